@@ -1,0 +1,192 @@
+/*
+ * ofdg.h -- C-ABI of the MI355X-native optical-flow data generator.
+ *
+ * This is the drop-in boundary for the reference's per-sample hot path
+ * (blueprint -> masks -> warped textures -> composited image0/image1 + flow).
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point names the reference interface it replaces.  Citations are
+ * relative to the reference repository root
+ * (lmb-freiburg/optical-flow-2d-data-generation):
+ *   DG  = src/caffe/DataGenerator.cpp
+ *   DGH = include/caffe/data_generation/DataGenerator.h
+ *   LAY = src/caffe/layers/data_generation_layer.cpp
+ *   WF  = src/caffe/WarpFields.cpp
+ */
+#ifndef OFDG_H_
+#define OFDG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Error codes (reference: std::runtime_error / glog CHECK, DG:121,    */
+/* DG:1143, DG:2004; silently dropped "bad" samples DG:1285-1292).     */
+/* ------------------------------------------------------------------ */
+#define OFDG_OK          0
+#define OFDG_EBADMODE   (-1) /* "BAD MODE"                      DG:2004  */
+#define OFDG_ETEXTURES  (-2) /* "Could not open texture ..."    DG:121   */
+#define OFDG_EOBJTYPE   (-3) /* "Bad object type ..."           DG:1143  */
+#define OFDG_EHIP       (-4) /* HIP runtime failure / extension missing  */
+#define OFDG_ECAPACITY  (-5) /* fixed-capacity array exceeded            */
+#define OFDG_EINVAL     (-6) /* invalid argument                         */
+
+/* ObjType_t (DGH:369-374) and PolySegmentType_t (DGH:377-381) values. */
+#define OFDG_OBJ_DUMMY     0
+#define OFDG_OBJ_ELLIPSE   1
+#define OFDG_OBJ_POLYGON   2
+#define OFDG_OBJ_COMPOSITE 3
+#define OFDG_SEG_DUMMY     0
+#define OFDG_SEG_LINE      1
+#define OFDG_SEG_CURVE3    3
+
+#define OFDG_MAX_SEGMENTS    20 /* RNG_PolyObj_spokes in [3,20]   DG:1687 */
+#define OFDG_MAX_COMPONENTS   8 /* RNG_CompObiNumberOfComponents <= 7     */
+#define OFDG_BACKGROUND_ID    1 /* BACKGROUND_OBJ_ID              DGH:60  */
+
+/* sampler kinds */
+#define OFDG_SAMPLER_REF      0 /* bit-identical 45-stream mt19937 sampler */
+#define OFDG_SAMPLER_COUNTER  1 /* device counter-based sampler            */
+
+/*
+ * POD mirror of DataGenerator::ObjectBlueprint (DGH:388-421).  Children of a
+ * composite live in the same flat array (first_component, n_components)
+ * instead of owning heap pointers (DG:934-940).
+ */
+typedef struct ofdg_blueprint {
+  int32_t obj_id;
+  int32_t obj_type;
+  float   init_rot, init_scale, init_trans_x, init_trans_y;
+  float   rot, scale, trans_x, trans_y;
+  int32_t tex_id;
+  float   tex_rot, tex_scale;
+  int32_t tex_shift_x, tex_shift_y;
+  float   ellipse_scale_x, ellipse_scale_y;
+  int32_t n_segments;
+  int32_t segment_type[OFDG_MAX_SEGMENTS];
+  float   segment_x[OFDG_MAX_SEGMENTS];
+  float   segment_y[OFDG_MAX_SEGMENTS];
+  int32_t first_component;
+  int32_t n_components;
+  int32_t is_additive_component;
+  int32_t do_warpfield_deformation;
+} ofdg_blueprint;
+
+/*
+ * POD mirror of DataGenerator::TaskBucket (DGH:423-437): one sample = one
+ * background blueprint + n_objects top-level foreground blueprints, which are
+ * contiguous in the flat blueprint array.
+ */
+typedef struct ofdg_task {
+  int32_t background;   /* index of the background blueprint */
+  int32_t first_object; /* index of the first top-level foreground blueprint */
+  int32_t n_objects;
+  int32_t reserved;
+} ofdg_task;
+
+/*
+ * Options: data_param{batch_size,prefetch} + data_generation_param{mode,
+ * first_level_threads, second_level_threads, use_antialiasing}
+ * (src/caffe/proto/caffe.proto:6-12, example-prototxt/train.prototxt:9-30)
+ * plus extension keys (width/height are #defines in the reference, DGH:55-56).
+ */
+typedef struct ofdg_params {
+  int32_t width;                /* DGEN_WIDTH  (512) */
+  int32_t height;               /* DGEN_HEIGHT (384) */
+  int32_t mode;                 /* 1..13 */
+  int32_t use_antialiasing;     /* default 1 */
+  int32_t batch_size;
+  int32_t prefetch;
+  int32_t first_level_threads;  /* accepted; only used by CPU paths */
+  int32_t second_level_threads; /* accepted; only used by CPU paths */
+  int32_t num_objects;          /* 0 = reference behaviour (16..23, DG:1666) */
+  int32_t sampler;              /* OFDG_SAMPLER_* */
+  int32_t seed;                 /* counter sampler seed; ref sampler uses 0..44 */
+  int32_t rank, world_size;     /* sample sharding (g = step*B*world + rank*B + i) */
+  int32_t device;               /* HIP device ordinal */
+  int32_t max_shapes_per_sample;/* 0 = default capacity */
+  int32_t reserved[9];
+} ofdg_params;
+
+typedef struct ofdg_ctx ofdg_ctx;
+
+/* Fill *p with the reference's defaults (caffe.proto:6-12, DGH:55-56). */
+void ofdg_default_params(ofdg_params* p);
+
+/*
+ * Replaces DataGenerationLayer ctor + LayerSetUp (LAY:36-56, 106-132):
+ * DataGenerator(param) + ObjectParametersGenerator(param) (DG:990-998,
+ * DG:1358-2054).  Fails with OFDG_EHIP if no HIP device / kernel image.
+ */
+int ofdg_create(const ofdg_params* params, ofdg_ctx** out);
+void ofdg_destroy(ofdg_ctx* ctx);
+/* Message of the last failure on this ctx (or of a failed ofdg_create if ctx==NULL). */
+const char* ofdg_last_error(const ofdg_ctx* ctx);
+
+/* ---- texture pool: replaces TextureCollection (DG:117-161) ---------------- */
+/* n seeded synthetic w x h textures generated directly in HBM. */
+int ofdg_pool_synthetic(ofdg_ctx* ctx, int n, int w, int h, uint32_t seed);
+/* Reserve an empty pool of n textures of w x h, to be filled by ofdg_pool_upload. */
+int ofdg_pool_alloc(ofdg_ctx* ctx, int n, int w, int h);
+/* Upload one texture: planar B,G,R u8 (CImg layout after the swap at DG:129-131). */
+int ofdg_pool_upload(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, int w, int h);
+/* Download texture `index` as planar B,G,R u8 (w*h*3 bytes). */
+int ofdg_pool_download(ofdg_ctx* ctx, int index, uint8_t* bgr_planar);
+int ofdg_pool_info(const ofdg_ctx* ctx, int* n, int* w, int* h);
+
+/*
+ * Replaces the sampling half of load_batch (LAY:197-213):
+ * generateBackground / generateNumberOfFgObjects / generateForegroundObject
+ * (DG:2105-2835).  Appends n_tasks tasks; blueprints go to bps[0..*n_bps).
+ * OFDG_SAMPLER_REF continues the 45 seeded streams of this ctx.
+ */
+int ofdg_sample(ofdg_ctx* ctx, int n_tasks, ofdg_task* tasks,
+                ofdg_blueprint* bps, int bps_capacity, int* n_bps);
+
+/*
+ * THE HOT PATH.  Replaces commissionNewTask + Process_TaskBucket +
+ * retrieveFinishedTask (DG:1175-1254, 1308-1349) and the batch assembly of
+ * load_batch (LAY:227-250).  Renders task i into slot i of the caller-owned
+ * DEVICE buffers image0 [n,3,H,W], image1 [n,3,H,W], flow [n,2,H,W] (float32,
+ * planar, B,G,R order, 0..255).  Asynchronous on `stream` (a hipStream_t).
+ */
+int ofdg_render(ofdg_ctx* ctx, const ofdg_task* tasks, int n_tasks,
+                const ofdg_blueprint* bps, int n_bps,
+                float* d_image0, float* d_image1, float* d_flow, void* stream);
+
+/* Re-run the device half of the last ofdg_render (geometry already resident in
+ * HBM): used to time the path with inputs resident, and for hipGraph replay. */
+int ofdg_render_resident(ofdg_ctx* ctx, float* d_image0, float* d_image1,
+                         float* d_flow, void* stream);
+
+/* Replaces Forward_cpu/Forward_gpu (LAY:266-291): sample batch_size tasks and
+ * render them. */
+int ofdg_forward(ofdg_ctx* ctx, float* d_image0, float* d_image1, float* d_flow,
+                 void* stream);
+
+/* Wait for `stream` and report device-side error flags raised by kernels. */
+int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
+
+/* ---- inspection (tests / profiling) ---------------------------------------- */
+/* Rasterise one polygon (n double vertices, already in screen space) with the
+ * device rasteriser and return the raw AGG coverage (0..255) as w*h bytes. */
+int ofdg_debug_rasterize(ofdg_ctx* ctx, const double* xy, int n_vertices,
+                         uint8_t* coverage_host);
+/* After ofdg_render: raw coverage of rasterised shape `shape` of sample
+ * `sample`, frame 0/1, as w*h host bytes (zero outside its bounding box). */
+int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
+                        uint8_t* coverage_host);
+int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
+/* Per-kernel device time (ms) of the last render, measured with HIP events on
+ * the launch stream when profiling is enabled. names: "geom","raster","compose". */
+int ofdg_set_profiling(ofdg_ctx* ctx, int enabled);
+int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDG_H_ */

@@ -1,0 +1,515 @@
+// TEST INFRASTRUCTURE -- parity oracle, not product code.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// import, call, link or execute anything under oracle/.  The product
+// (optical-flow-2d-data-generation_amd/) never links this file.
+//
+// CPU restatement of the reference's hot path, one sample at a time, in the
+// reference's own structure (per-object full-frame masks and textures, painter's
+// blit, per-pixel flow):  DataGenerator::Process_TaskBucket and everything it
+// calls (src/caffe/DataGenerator.cpp:1175-1254).  Citations "DG:" are into
+// src/caffe/DataGenerator.cpp of the reference.
+//
+// Parity status: the sampler's RNG layer is pinned against the reference's own
+// SimpleRandom.h compiled here (oracle/_ref, tests/golden/rng_goldens.json) and
+// against the blueprint values recorded in SURVEY.md Appendix E.1; rasteriser,
+// curve flattening and DDA are pinned against matplotlib's compiled AGG
+// (tests/golden/agg_goldens.npz).  The reference as a whole cannot be built here
+// (Caffe, AGG 2.4 and CImg are absent), so the remaining pieces
+// (gray8 blend byte mapping, bilinear weights, reflect wrap, CImg draw_image)
+// follow the libraries' published source: "parity unpinned" for those.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+
+#include "../include/ofdg.h"
+#include "oracle_core.h"
+#include "oracle_sampler.h"
+#include "oracle_warpfields.h"
+
+using namespace oracle;
+
+namespace {
+
+struct Pool {
+  int n = 0, w = 0, h = 0;
+  const uint8_t* data = nullptr;  // n * 3 * h * w, planar B,G,R per texture
+  const uint8_t* tex(int raw_index) const {  // TextureCollection::getTexturePtr, DG:158-161
+    return data + (size_t)(raw_index % n) * 3 * w * h;
+  }
+};
+
+// Texture::getRandomizedCrop with default arguments (DG:87-109 called at
+// DG:1149-1150): get_shift(0,0), rotate(0), crop(w/2-W/2, h/2-H/2, +W-1, +H-1),
+// resize(W,H) -- all identities except the centre crop.
+std::vector<uint8_t> centre_crop(const Pool& pool, int raw_index, int cw, int ch) {
+  std::vector<uint8_t> out((size_t)3 * cw * ch);
+  const uint8_t* t = pool.tex(raw_index);
+  const int x0 = pool.w / 2 - cw / 2, y0 = pool.h / 2 - ch / 2;
+  for (int c = 0; c < 3; ++c)
+    for (int y = 0; y < ch; ++y)
+      std::memcpy(&out[((size_t)c * ch + y) * cw], t + ((size_t)c * pool.h + (y0 + y)) * pool.w + x0, cw);
+  return out;
+}
+
+ShapeGeom geom_of(const ofdg_blueprint& p) {  // DG:1073-1117
+  ShapeGeom g;
+  g.type = p.obj_type;
+  g.rx = p.ellipse_scale_x;
+  g.ry = p.ellipse_scale_y;
+  g.n_seg = p.n_segments;
+  for (int i = 0; i < p.n_segments; ++i) {
+    g.seg_type[i] = p.segment_type[i];
+    g.seg_x[i] = p.segment_x[i];
+    g.seg_y[i] = p.segment_y[i];
+  }
+  return g;
+}
+
+// One MovingObject* (DG:256-718) with its four masks and two warped textures.
+struct Object {
+  int id = 0;
+  bool is_background = false;
+  Affine intrinsic, intrinsic_inv, motion, motion_inv;
+  std::vector<uint8_t> mask_noAA[2], mask_AA[2];
+  std::vector<uint8_t> tex[3];  // m_textures[0..2]
+  bool has_warp = false;
+  const WarpCrop* warp = nullptr;
+  std::unique_ptr<WarpCrop> own_warp;  // background's upscaled copy
+};
+
+struct Ctx {
+  int W, H, mode;
+  bool use_AA;
+  bool faithful;  // 4 rasterisations per shape like the reference (cost model)
+};
+
+void set_intrinsic(Object& o, float alpha, float xs, float ys) {  // DG:302-310
+  o.intrinsic = Affine();
+  o.intrinsic *= Affine::rotation(alpha);
+  o.intrinsic *= Affine::translation(xs, ys);
+  o.intrinsic_inv = o.intrinsic;
+  o.intrinsic_inv.invert();
+}
+void set_motion(Object& o, float alpha, float scale, float xs, float ys) {  // DG:312-322
+  o.motion = Affine();
+  o.motion *= Affine::rotation(alpha);
+  o.motion *= Affine::scaling(scale);
+  o.motion *= Affine::translation(xs, ys);
+  o.motion_inv = o.motion;
+  o.motion_inv.invert();
+}
+void add_background_motion(Object& o, const Affine& bg_motion, int W, int H) {  // DG:324-335
+  Affine bg_n = Affine::translation(-W / 2., -H / 2.);
+  bg_n *= bg_motion;
+  bg_n *= Affine::translation(W / 2., H / 2.);
+  o.motion *= bg_n;
+  o.motion_inv = o.motion;
+  o.motion_inv.invert();
+}
+
+// MovingObjectBase::draw (DG:351-368): rasterise, gray8-blend onto cleared scratch.
+void draw(const Ctx& c, const std::vector<PointD>& poly, bool AA, std::vector<uint8_t>& mask, bool* ok) {
+  std::vector<uint8_t> cov((size_t)c.W * c.H);
+  if (!rasterize_polygon(poly, c.W, c.H, cov.data(), !AA)) *ok = false;
+  mask.resize(cov.size());
+  for (size_t i = 0; i < cov.size(); ++i) mask[i] = gray8_solid_on_clear(cov[i]);
+}
+
+// applyWarpFieldToTexture (DG:237-252) for `channels` planes of W x H.
+void apply_warp(const std::vector<uint8_t>& in, int W, int H, int channels, const WarpCrop& wc, bool inverse,
+                std::vector<uint8_t>& out) {
+  out.resize(in.size());
+  const std::vector<float>& f = inverse ? wc.iflow : wc.flow;
+  for (int ch = 0; ch < channels; ++ch)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float fx = x + f[(size_t)y * wc.w + x];
+        float fy = y + f[(size_t)wc.w * wc.h + (size_t)y * wc.w + x];
+        out[((size_t)ch * H + y) * W + x] = cimg_linear_atXY_dirichlet_u8(&in[(size_t)ch * W * H], W, H, fx, fy);
+      }
+}
+
+// renderMasks (DG:465-479 ellipse, DG:520-534 polygon, DG:370-386 warp part).
+void render_shape_masks(const Ctx& c, Object& o, const ShapeGeom& g, bool* ok) {
+  Affine save = o.intrinsic;
+  save *= o.motion;
+  std::vector<PointD> p0 = outline(g, o.intrinsic);
+  std::vector<PointD> p1 = outline(g, save);
+  draw(c, p0, true, o.mask_AA[0], ok);
+  draw(c, p0, false, o.mask_noAA[0], ok);
+  draw(c, p1, true, o.mask_AA[1], ok);
+  draw(c, p1, false, o.mask_noAA[1], ok);
+  if (o.has_warp) {
+    std::vector<uint8_t> t;
+    apply_warp(o.mask_noAA[1], c.W, c.H, 1, *o.warp, true, t);
+    o.mask_noAA[1].swap(t);
+    apply_warp(o.mask_AA[1], c.W, c.H, 1, *o.warp, true, t);
+    o.mask_AA[1].swap(t);
+  }
+}
+
+// renderTransformedTexture (DG:337-349)
+void render_textures(const Ctx& c, Object& o) {
+  o.tex[1].resize(o.tex[0].size());
+  o.tex[2].resize(o.tex[0].size());
+  transformed_texture(o.tex[0].data(), c.W, c.H, Affine(), o.tex[1].data());
+  transformed_texture(o.tex[0].data(), c.W, c.H, o.motion, o.tex[2].data());
+  if (o.has_warp) {
+    std::vector<uint8_t> t;
+    apply_warp(o.tex[2], c.W, c.H, 3, *o.warp, true, t);
+    o.tex[2].swap(t);
+  }
+}
+
+// MovingObjectBackground (DG:654-718)
+void render_background(const Ctx& c, Object& o) {
+  const int W = c.W, H = c.H, W2 = 2 * W, H2 = 2 * H;
+  std::vector<uint8_t> t1(o.tex[0].size()), t2(o.tex[0].size());
+  transformed_texture(o.tex[0].data(), W2, H2, Affine(), t1.data());
+  Affine m = o.intrinsic_inv * o.motion * o.intrinsic;  // DG:673,677
+  transformed_texture(o.tex[0].data(), W2, H2, m, t2.data());
+  if (o.has_warp) {
+    std::vector<uint8_t> t;
+    apply_warp(t2, W2, H2, 3, *o.warp, true, t);
+    t2.swap(t);
+  }
+  // crop(W/2., H/2., W*3./2.-1, H*3./2.-1) (DG:680-681)
+  const int cx = (int)(W / 2.), cy = (int)(H / 2.);
+  o.tex[1].resize((size_t)3 * W * H);
+  o.tex[2].resize((size_t)3 * W * H);
+  for (int ch = 0; ch < 3; ++ch)
+    for (int y = 0; y < H; ++y) {
+      std::memcpy(&o.tex[1][((size_t)ch * H + y) * W], &t1[((size_t)ch * H2 + y + cy) * W2 + cx], W);
+      std::memcpy(&o.tex[2][((size_t)ch * H + y) * W], &t2[((size_t)ch * H2 + y + cy) * W2 + cx], W);
+    }
+  for (int f = 0; f < 2; ++f) {  // renderMasks, DG:684-690
+    o.mask_AA[f].assign((size_t)W * H, 255);
+    o.mask_noAA[f].assign((size_t)W * H, 255);
+  }
+}
+
+// getPointFlow (DG:388-407 / DG:692-718)
+void point_flow(const Ctx& c, const Object& o, float* x, float* y) {
+  if (!o.is_background) {
+    double ix = *x, iy = *y;
+    float save_x = ix, save_y = iy;
+    o.motion.transform(&ix, &iy);
+    *x = ix - save_x;
+    *y = iy - save_y;
+    if (o.has_warp and ix >= 0 and ix < c.W and iy >= 0 and iy < c.H) {
+      *x += cimg_linear_atXY_neumann(o.warp->flow.data(), o.warp->w, o.warp->h, ix, iy);
+      *y += cimg_linear_atXY_neumann(o.warp->flow.data() + (size_t)o.warp->w * o.warp->h, o.warp->w, o.warp->h, ix, iy);
+    }
+  } else {
+    double ix = *x + c.W / 2, iy = *y + c.H / 2;
+    float save_x = ix, save_y = iy;
+    o.intrinsic_inv.transform(&ix, &iy);
+    o.motion.transform(&ix, &iy);
+    o.intrinsic.transform(&ix, &iy);
+    *x = ix - save_x;
+    *y = iy - save_y;
+    if (o.has_warp and ix >= 0 and ix < 2 * c.W and iy >= 0 and iy < 2 * c.H) {
+      *x += cimg_linear_atXY_neumann(o.warp->flow.data(), o.warp->w, o.warp->h, ix, iy);
+      *y += cimg_linear_atXY_neumann(o.warp->flow.data() + (size_t)o.warp->w * o.warp->h, o.warp->w, o.warp->h, ix, iy);
+    }
+  }
+}
+
+struct Scene {
+  std::map<size_t, std::unique_ptr<Object>> objects;  // objects_map (ascending ID)
+  std::vector<std::unique_ptr<Object>> components;    // kept alive for inspection
+  std::vector<const Object*> shape_order;             // rasterised shapes in realisation order
+};
+
+// RealizeObjectBlueprint (DG:1065-1173)
+Object* realize(const Ctx& c, const ofdg_blueprint* bps, int bi, const Affine& bg_motion, const Pool& pool,
+                WarpSource* warps, Scene& scene, Object* parent, bool* ok) {
+  const ofdg_blueprint& p = bps[bi];
+  std::unique_ptr<Object> obj(new Object());
+  Object* o = obj.get();
+  o->id = parent ? 0 : p.obj_id;  // Component classes use ID 0 (DG:542-544, 555-557)
+  std::vector<Object*> comps;
+  std::vector<bool> comp_modes;
+  if (p.obj_type == OFDG_OBJ_COMPOSITE) {
+    if (c.mode == 9 and p.do_warpfield_deformation) {  // DG:1120-1128
+      o->warp = warps->get_crop();
+      o->has_warp = true;
+    }
+    if (parent) scene.components.push_back(std::move(obj)); else scene.objects[o->id] = std::move(obj);
+    for (int k = 0; k < p.n_components; ++k) {
+      Object* co = realize(c, bps, p.first_component + k, bg_motion, pool, warps, scene, o, ok);
+      comps.push_back(co);
+      comp_modes.push_back(bps[p.first_component + k].is_additive_component != 0);
+    }
+  } else if (p.obj_type == OFDG_OBJ_ELLIPSE or p.obj_type == OFDG_OBJ_POLYGON) {
+    if (parent) scene.components.push_back(std::move(obj)); else scene.objects[o->id] = std::move(obj);
+  } else {
+    *ok = false;  // "(RealizeObjectBlueprint) Bad object type" DG:1143
+    return nullptr;
+  }
+  o->tex[0] = centre_crop(pool, p.tex_id, c.W, c.H);  // DG:1149-1150
+  set_intrinsic(*o, p.init_rot, p.init_trans_x, p.init_trans_y);
+  set_motion(*o, p.rot, p.scale, p.trans_x, p.trans_y);
+  add_background_motion(*o, bg_motion, c.W, c.H);
+  if (c.mode == 9 and p.do_warpfield_deformation) {  // DG:1157-1169
+    if (parent) {
+      o->warp = parent->warp;
+      o->has_warp = parent->has_warp;
+    } else if (not o->has_warp) {
+      o->warp = warps->get_crop();
+      o->has_warp = true;
+    }
+  }
+  // Process_UnfinishedObjectContainer (DG:726-732)
+  if (!parent) render_textures(c, *o);  // Component*::renderTransformedTexture is empty (DG:546-560)
+  if (p.obj_type == OFDG_OBJ_COMPOSITE) {
+    // MovingObjectComposite::renderMasks (DG:591-646)
+    const size_t n = (size_t)c.W * c.H;
+    for (int f = 0; f < 2; ++f) { o->mask_AA[f].assign(n, 0); o->mask_noAA[f].assign(n, 0); }
+    for (size_t ci = 0; ci < comps.size(); ++ci) {
+      Object* co = comps[ci];
+      for (int f = 0; f < 2; ++f) {
+        for (size_t i = 0; i < n; ++i) {
+          if (comp_modes[ci]) {
+            o->mask_noAA[f][i] = composite_add(o->mask_noAA[f][i], co->mask_noAA[f][i]);
+            o->mask_AA[f][i] = composite_add(o->mask_AA[f][i], co->mask_AA[f][i]);
+          } else {
+            o->mask_noAA[f][i] = composite_sub(o->mask_noAA[f][i], co->mask_noAA[f][i]);
+            o->mask_AA[f][i] = composite_sub(o->mask_AA[f][i], co->mask_AA[f][i]);
+          }
+        }
+      }
+    }
+  } else {
+    scene.shape_order.push_back(o);
+    render_shape_masks(c, *o, geom_of(p), ok);
+  }
+  return o;
+}
+
+// Process_TaskBucket (DG:1175-1254) for one task.  bg_tex: optional explicit
+// 2W x 2H background texture m_textures[0] (planar BGR); if null, the parity
+// boundary's "centre crop" preparation is used (angle 0, zoom 1, shift 0).
+bool process_task(const Ctx& c, const ofdg_task& task, const ofdg_blueprint* bps, const Pool& pool,
+                  WarpSource* warps, float* img0, float* img1, float* flow, Scene* keep_scene) {
+  const int W = c.W, H = c.H;
+  const size_t n = (size_t)W * H;
+  bool ok = true;
+  Scene local;
+  Scene& scene = keep_scene ? *keep_scene : local;
+  // background (DG:1183-1205)
+  const ofdg_blueprint& pb = bps[task.background];
+  {
+    std::unique_ptr<Object> bg(new Object());
+    bg->id = pb.obj_id;
+    bg->is_background = true;
+    set_intrinsic(*bg, 0.f, W, H);  // DG:662
+    bg->tex[0] = centre_crop(pool, pb.tex_id, 2 * W, 2 * H);
+    set_motion(*bg, pb.rot, pb.scale, pb.trans_x, pb.trans_y);
+    if (c.mode == 9 and pb.do_warpfield_deformation) {  // DG:1194-1202
+      const WarpCrop* crop = warps->get_crop();
+      bg->own_warp.reset(new WarpCrop(upscale_warp_for_background(*crop, 2 * W, 2 * H)));
+      bg->warp = bg->own_warp.get();
+      bg->has_warp = true;
+    }
+    render_background(c, *bg);
+    scene.objects[bg->id] = std::move(bg);
+  }
+  const Affine bg_motion = scene.objects[pb.obj_id]->motion;
+  for (int i = 0; i < task.n_objects; ++i)
+    realize(c, bps, task.first_object + i, bg_motion, pool, warps, scene, nullptr, &ok);
+  if (!ok) return false;
+
+  // RenderCore::blitObject in ascending ID (DG:762-799, 1216-1223)
+  std::vector<uint8_t> frame0(3 * n, 0), frame1(3 * n, 0);
+  std::vector<size_t> index0(n, 0);
+  for (auto& kv : scene.objects) {
+    const Object& o = *kv.second;
+    for (size_t i = 0; i < n; ++i)
+      if (o.mask_noAA[0][i] == 255) index0[i] = o.id;
+    const std::vector<uint8_t>& m0 = c.use_AA ? o.mask_AA[0] : o.mask_noAA[0];
+    const std::vector<uint8_t>& m1 = c.use_AA ? o.mask_AA[1] : o.mask_noAA[1];
+    for (int ch = 0; ch < 3; ++ch)
+      for (size_t i = 0; i < n; ++i) {
+        frame0[ch * n + i] = draw_image_value(frame0[ch * n + i], o.tex[1][ch * n + i], m0[i]);
+        frame1[ch * n + i] = draw_image_value(frame1[ch * n + i], o.tex[2][ch * n + i], m1[i]);
+      }
+  }
+  // computeFlowImage(objects_map, false) (DG:801-818)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      size_t idx = index0[(size_t)y * W + x];
+      float xf = x, yf = y;
+      if (idx == 0) { flow[(size_t)y * W + x] = 0.f; flow[n + (size_t)y * W + x] = 0.f; continue; }
+      point_flow(c, *scene.objects[idx], &xf, &yf);
+      flow[(size_t)y * W + x] = xf;
+      flow[n + (size_t)y * W + x] = yf;
+    }
+  for (size_t i = 0; i < 3 * n; ++i) {  // DG:1229-1244
+    img0[i] = static_cast<float>(frame0[i]);
+    img1[i] = static_cast<float>(frame1[i]);
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- RNG probes (G2) ----------------------------------------------------------
+// kind: 0 FixedRangeUniformInt(a,b) 1 FixedRangeUniformFloat(a,b) 2 Normal(0,1)
+//       3 GaussianSq(a,b) 4 Gaussian3(a,b) 5 Gaussian4(a,b) 6 Trigger(a,b,thr=c)
+void ofdg_oracle_rng_draws(int kind, int seed, double a, double b, double c, int n, double* out) {
+  switch (kind) {
+    case 0: { FixedRangeUniformInt r((int)a, (int)b, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 1: { FixedRangeUniformFloat r(a, b, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 2: { FixedMeanStddevNormalFloat r(0, 1, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 3: { GaussianSq r(a, b, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 4: { Gaussian3 r(a, b, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 5: { Gaussian4 r(a, b, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+    case 6: { Trigger r(a, b, c, seed); for (int i = 0; i < n; ++i) out[i] = r(); break; }
+  }
+}
+
+// ---- sampler ---------------------------------------------------------------------
+void* ofdg_oracle_sampler_create(int mode, int W, int H, int num_objects) {
+  try { return new Sampler(mode, W, H, num_objects); } catch (...) { return nullptr; }
+}
+void ofdg_oracle_sampler_destroy(void* s) { delete (Sampler*)s; }
+// Samples n_tasks tasks; returns the number of blueprints written or -needed.
+int ofdg_oracle_sampler_next(void* s, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps, int cap) {
+  Sampler* sm = (Sampler*)s;
+  std::vector<ofdg_blueprint> pool;
+  for (int i = 0; i < n_tasks; ++i) sm->next_task(pool, &tasks[i]);
+  if ((int)pool.size() > cap) return -(int)pool.size();
+  std::memcpy(bps, pool.data(), pool.size() * sizeof(ofdg_blueprint));
+  return (int)pool.size();
+}
+
+// ---- geometry / rasteriser probes (G3, G4, G5) ----------------------------------
+int ofdg_oracle_rasterize(const double* xy, int n, int w, int h, uint8_t* cov) {
+  std::vector<PointD> p(n);
+  for (int i = 0; i < n; ++i) p[i] = {xy[2 * i], xy[2 * i + 1]};
+  return rasterize_polygon(p, w, h, cov, false) ? 0 : -1;
+}
+int ofdg_oracle_curve3(double x1, double y1, double x2, double y2, double x3, double y3, double* out_xy, int cap) {
+  Curve3Div c;
+  c.init(x1, y1, x2, y2, x3, y3);
+  if ((int)c.pts.size() > cap) return -(int)c.pts.size();
+  for (size_t i = 0; i < c.pts.size(); ++i) { out_xy[2 * i] = c.pts[i].x; out_xy[2 * i + 1] = c.pts[i].y; }
+  return (int)c.pts.size();
+}
+// Outline of a blueprint's shape under m (6 doubles sx,shy,shx,sy,tx,ty).
+int ofdg_oracle_outline(const ofdg_blueprint* bp, const double* m, double* out_xy, int cap) {
+  Affine a(m[0], m[1], m[2], m[3], m[4], m[5]);
+  std::vector<PointD> p = outline(geom_of(*bp), a);
+  if ((int)p.size() > cap) return -(int)p.size();
+  for (size_t i = 0; i < p.size(); ++i) { out_xy[2 * i] = p[i].x; out_xy[2 * i + 1] = p[i].y; }
+  return (int)p.size();
+}
+// span_interpolator_linear + dda2: per-pixel (x_hr, y_hr) of row y, before the -128.
+void ofdg_oracle_dda_row(const double* inv, int y, int len, int* out_xy) {
+  Affine a(inv[0], inv[1], inv[2], inv[3], inv[4], inv[5]);
+  double tx = 0.5, ty = y + 0.5;
+  a.transform(&tx, &ty);
+  int x1 = iround(tx * 256), y1 = iround(ty * 256);
+  tx = 0.5 + len; ty = y + 0.5;
+  a.transform(&tx, &ty);
+  int x2 = iround(tx * 256), y2 = iround(ty * 256);
+  Dda2 lx(x1, x2, len), ly(y1, y2, len);
+  for (int i = 0; i < len; ++i) { out_xy[2 * i] = lx.y; out_xy[2 * i + 1] = ly.y; ++lx; ++ly; }
+}
+void ofdg_oracle_transformed_texture(const uint8_t* in, int tw, int th, const double* m, uint8_t* out) {
+  transformed_texture(in, tw, th, Affine(m[0], m[1], m[2], m[3], m[4], m[5]), out);
+}
+// exhaustive tables for the composite formulas and the blends (65536 entries each)
+void ofdg_oracle_tables(uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_byte) {
+  for (int u = 0; u < 256; ++u)
+    for (int v = 0; v < 256; ++v) {
+      add_tbl[u * 256 + v] = composite_add(u, v);
+      sub_tbl[u * 256 + v] = composite_sub(u, v);
+    }
+  for (int c = 0; c < 256; ++c) aa_byte[c] = gray8_solid_on_clear(c);
+}
+uint8_t ofdg_oracle_draw_image_value(uint8_t d, uint8_t s, uint8_t m) { return draw_image_value(d, s, m); }
+
+// ---- warp fields (mode 9) ----------------------------------------------------------
+// displacers: n x 11 doubles {type, p0, p1, p2, sup_cx, sup_cy, sup_sx, sup_sy, sup_angle, 0, 0}
+// (type 0 Translation(dx,dy); 1 Rotation(cx,cy,omega); 2 Zoom(cx,cy,factor)).
+int ofdg_oracle_flowfield(int size, const double* displacers, int n, int iters, float* flow, float* iflow) {
+  std::vector<DisplacerSpec> d(n);
+  for (int i = 0; i < n; ++i) std::memcpy(&d[i], displacers + (size_t)i * 11, sizeof(double) * 9);
+  FlowField ff;
+  ff.init_from_displacers(size, size, d, iters);
+  ff.clamp_near_zeros();
+  std::memcpy(flow, ff.flow.data(), ff.flow.size() * 4);
+  std::memcpy(iflow, ff.iflow.data(), ff.iflow.size() * 4);
+  return 0;
+}
+
+// ---- the hot path ---------------------------------------------------------------------
+// flags: bit0 = faithful cost (unused yet: always the reference's per-object structure)
+// warp_crops: for mode 9, n_crops crops of (W+1)x(H+1) {flow[2], iflow[2]} served in
+// order, each `reuse` times in a row (CropGenerator::get_crop, WarpFields.cpp:516-538).
+int ofdg_oracle_render(const ofdg_params* prm, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
+                       int n_bps, const uint8_t* pool_data, int pool_n, int pool_w, int pool_h,
+                       const float* warp_crops, int n_crops, int reuse,
+                       float* img0, float* img1, float* flow, int n_threads) {
+  (void)n_bps;
+  Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
+  Pool pool{pool_n, pool_w, pool_h, pool_data};
+  if (pool_w < 2 * c.W || pool_h < 2 * c.H) return OFDG_ETEXTURES;
+  const size_t n = (size_t)c.W * c.H;
+  WarpSource warps(warp_crops, n_crops, c.W + 1, c.H + 1, reuse);
+  int rc = OFDG_OK;
+  if (n_threads <= 1 || c.mode == 9) {
+    for (int i = 0; i < n_tasks; ++i)
+      if (!process_task(c, tasks[i], bps, pool, &warps, img0 + 3 * n * i, img1 + 3 * n * i, flow + 2 * n * i, nullptr))
+        rc = OFDG_EOBJTYPE;
+  } else {
+    // first_level_threads sample workers (DG:1023-1027); tasks are independent.
+    std::vector<std::thread> th;
+    std::vector<int> rcs(n_threads, OFDG_OK);
+    for (int t = 0; t < n_threads; ++t)
+      th.emplace_back([&, t] {
+        WarpSource none(nullptr, 0, 0, 0, 0);
+        for (int i = t; i < n_tasks; i += n_threads)
+          if (!process_task(c, tasks[i], bps, pool, &none, img0 + 3 * n * i, img1 + 3 * n * i, flow + 2 * n * i, nullptr))
+            rcs[t] = OFDG_EOBJTYPE;
+      });
+    for (auto& t : th) t.join();
+    for (int r : rcs) if (r != OFDG_OK) rc = r;
+  }
+  return rc;
+}
+
+// Raw masks of the rasterised shapes of ONE task, in realisation order (components
+// first, depth-first, as RealizeObjectBlueprint recurses).  kind: 0 AA0 1 AA1 2 noAA0 3 noAA1.
+int ofdg_oracle_shape_masks(const ofdg_params* prm, const ofdg_task* task, const ofdg_blueprint* bps,
+                            const uint8_t* pool_data, int pool_n, int pool_w, int pool_h,
+                            uint8_t* masks, int max_shapes) {
+  Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
+  Pool pool{pool_n, pool_w, pool_h, pool_data};
+  const size_t n = (size_t)c.W * c.H;
+  std::vector<float> a(3 * n), b(3 * n), f(2 * n);
+  Scene scene;
+  WarpSource none(nullptr, 0, 0, 0, 0);
+  if (!process_task(c, *task, bps, pool, &none, a.data(), b.data(), f.data(), &scene)) return OFDG_EOBJTYPE;
+  int k = 0;
+  for (const Object* o : scene.shape_order) {
+    if (k >= max_shapes) break;
+    std::memcpy(masks + ((size_t)k * 4 + 0) * n, o->mask_AA[0].data(), n);
+    std::memcpy(masks + ((size_t)k * 4 + 1) * n, o->mask_AA[1].data(), n);
+    std::memcpy(masks + ((size_t)k * 4 + 2) * n, o->mask_noAA[0].data(), n);
+    std::memcpy(masks + ((size_t)k * 4 + 3) * n, o->mask_noAA[1].data(), n);
+    ++k;
+  }
+  return (int)scene.shape_order.size();
+}
+
+int ofdg_oracle_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+
+}  // extern "C"

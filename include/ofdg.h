@@ -183,8 +183,45 @@ int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
 int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
 /* Per-kernel device time (ms) of the last render, measured with HIP events on
  * the launch stream when profiling is enabled. names: "geom","raster","compose". */
+/* Exhaustive device evaluation of the per-byte formulas: composite add / subtract
+ * [u*256+v] (DG:606, 626), AA mask byte [c], draw_image blend [d*256+m] for s=s_fixed. */
+int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl,
+                      uint8_t* blend_tbl, int s_fixed);
 int ofdg_set_profiling(ofdg_ctx* ctx, int enabled);
 int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
+
+/* ---- host-side pieces (no HIP device needed) --------------------------------- */
+/* The reference-stream sampler on its own: ObjectParametersGenerator (DG:1358-2835)
+ * driven like load_batch (LAY:197-213). */
+typedef struct ofdg_host_sampler ofdg_host_sampler;
+int ofdg_host_sampler_create(int mode, int width, int height, int num_objects,
+                             ofdg_host_sampler** out);
+int ofdg_host_sampler_next(ofdg_host_sampler* s, int n_tasks, ofdg_task* tasks,
+                           ofdg_blueprint* bps, int bps_capacity, int* n_bps);
+void ofdg_host_sampler_destroy(ofdg_host_sampler* s);
+/* Blueprint -> fp64 affines exactly as RealizeObjectBlueprint / setMotion /
+ * addBackgroundMotion compute them (DG:302-335, 1065-1173).  shape_mats: 12 doubles
+ * per rasterised shape {intrinsic[6], intrinsic*motion[6]}; object_mats: 12 doubles
+ * per blitted object {motion[6], inverse texture warp[6]} (sx,shy,shx,sy,tx,ty). */
+int ofdg_host_realize(const ofdg_params* prm, int pool_n, int pool_w, int pool_h,
+                      const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
+                      int n_bps, double* shape_mats, int shape_cap, int* n_shapes,
+                      double* object_mats, int object_cap, int* n_objects);
+/* Parse a `layer { ... }` prototxt block (example-prototxt/train.prototxt). */
+int ofdg_parse_prototxt(const char* text, ofdg_params* out, char* texture_dbases,
+                        int texture_dbases_cap, int* n_top);
+const char* ofdg_host_last_error(void);
+
+/* ---- Caffe-layer-shaped surface: DataGenerationLayer (LAY:36-132, 266-291) ------ */
+typedef struct ofdg_layer ofdg_layer;
+/* ctor + LayerSetUp: parses the prototxt, opens the texture collection
+ * ("synthetic:N:W:H[:seed]" or a list file of binary PPMs), reshapes 3 tops. */
+int ofdg_layer_create(const char* layer_prototxt, ofdg_layer** out);
+/* Forward_gpu: returns the device pointers of image0/image1/flow and the
+ * shape {N,3,H,W} of image0. */
+int ofdg_layer_forward(ofdg_layer* layer, float** image0, float** image1, float** flow,
+                       int* shape4);
+void ofdg_layer_destroy(ofdg_layer* layer);
 
 #ifdef __cplusplus
 }

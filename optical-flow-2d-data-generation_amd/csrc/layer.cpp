@@ -1,0 +1,391 @@
+#include "layer.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+
+#include "realize.h"
+#include "sampler_ref.h"
+
+namespace ofdg {
+
+// ---------------------------------------------------------------------------
+// Blob
+// ---------------------------------------------------------------------------
+Blob::~Blob() {
+  if (data_) (void)hipFree(data_);
+}
+void Blob::Reshape(const std::vector<int>& shape) {
+  size_t n = 1;
+  for (int d : shape) {
+    if (d < 0) throw std::runtime_error("Blob::Reshape: negative dimension");
+    n *= (size_t)d;
+  }
+  shape_ = shape;
+  count_ = n;
+  if (n > capacity_) {
+    if (data_) (void)hipFree(data_);
+    data_ = nullptr;
+    if (hipMalloc((void**)&data_, n * sizeof(float)) != hipSuccess) throw std::runtime_error("Blob::Reshape: hipMalloc failed");
+    capacity_ = n;
+  }
+}
+size_t Blob::offset(int n, int c, int h, int w) const {
+  size_t o = (size_t)n;
+  o = o * (shape_.size() > 1 ? shape_[1] : 1) + c;
+  o = o * (shape_.size() > 2 ? shape_[2] : 1) + h;
+  o = o * (shape_.size() > 3 ? shape_[3] : 1) + w;
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// prototxt subset parser
+// ---------------------------------------------------------------------------
+namespace {
+struct Tok {
+  enum Kind { kIdent, kString, kNumber, kLBrace, kRBrace, kColon, kEnd } kind;
+  std::string text;
+};
+class Lexer {
+ public:
+  explicit Lexer(const std::string& s) : s_(s) {}
+  Tok next() {
+    for (;;) {
+      while (i_ < s_.size() && std::isspace((unsigned char)s_[i_])) ++i_;
+      if (i_ < s_.size() && s_[i_] == '#') { while (i_ < s_.size() && s_[i_] != '\n') ++i_; continue; }
+      break;
+    }
+    if (i_ >= s_.size()) return {Tok::kEnd, ""};
+    const char ch = s_[i_];
+    if (ch == '{') { ++i_; return {Tok::kLBrace, "{"}; }
+    if (ch == '}') { ++i_; return {Tok::kRBrace, "}"}; }
+    if (ch == ':') { ++i_; return {Tok::kColon, ":"}; }
+    if (ch == '"' || ch == '\'') {
+      const char q = ch;
+      std::string v;
+      ++i_;
+      while (i_ < s_.size() && s_[i_] != q) {
+        if (s_[i_] == '\\' && i_ + 1 < s_.size()) ++i_;
+        v += s_[i_++];
+      }
+      if (i_ >= s_.size()) throw std::runtime_error("prototxt: unterminated string");
+      ++i_;
+      return {Tok::kString, v};
+    }
+    if (std::isalpha((unsigned char)ch) || ch == '_') {
+      std::string v;
+      while (i_ < s_.size() && (std::isalnum((unsigned char)s_[i_]) || s_[i_] == '_')) v += s_[i_++];
+      return {Tok::kIdent, v};
+    }
+    if (std::isdigit((unsigned char)ch) || ch == '-' || ch == '+' || ch == '.') {
+      std::string v;
+      while (i_ < s_.size() && (std::isalnum((unsigned char)s_[i_]) || s_[i_] == '-' || s_[i_] == '+' || s_[i_] == '.')) v += s_[i_++];
+      return {Tok::kNumber, v};
+    }
+    throw std::runtime_error(std::string("prototxt: unexpected character '") + ch + "'");
+  }
+
+ private:
+  const std::string& s_;
+  size_t i_ = 0;
+};
+
+int to_int(const Tok& t, const std::string& key) {
+  if (t.kind == Tok::kIdent && (t.text == "true" || t.text == "false")) return t.text == "true";
+  if (t.kind != Tok::kNumber) throw std::runtime_error("prototxt: expected a number for " + key);
+  return (int)std::strtol(t.text.c_str(), nullptr, 10);
+}
+
+void parse_message(Lexer& lx, const std::string& scope, LayerConfig* cfg, bool top_level) {
+  for (;;) {
+    Tok k = lx.next();
+    if (k.kind == Tok::kEnd) {
+      if (!top_level) throw std::runtime_error("prototxt: missing '}'");
+      return;
+    }
+    if (k.kind == Tok::kRBrace) {
+      if (top_level) throw std::runtime_error("prototxt: unbalanced '}'");
+      return;
+    }
+    if (k.kind != Tok::kIdent) throw std::runtime_error("prototxt: expected a field name");
+    Tok v = lx.next();
+    if (v.kind == Tok::kColon) v = lx.next();
+    if (v.kind == Tok::kLBrace) {
+      parse_message(lx, scope.empty() ? k.text : scope + "." + k.text, cfg, false);
+      continue;
+    }
+    const std::string key = scope.empty() ? k.text : scope + "." + k.text;
+    ofdg_params& p = cfg->params;
+    if (key == "layer.name" || key == "name") cfg->name = v.text;
+    else if (key == "layer.type" || key == "type") cfg->type = v.text;
+    else if (key == "layer.top" || key == "top") cfg->top.push_back(v.text);
+    else if (key == "layer.data_param.batch_size" || key == "data_param.batch_size") p.batch_size = to_int(v, key);
+    else if (key == "layer.data_param.prefetch" || key == "data_param.prefetch") p.prefetch = to_int(v, key);
+    else if (key.find("data_generation_param.") != std::string::npos) {
+      const std::string f = key.substr(key.rfind('.') + 1);
+      if (f == "mode") p.mode = to_int(v, key);
+      else if (f == "texture_dbases") { if (cfg->texture_dbases.empty()) cfg->texture_dbases = v.text; }
+      else if (f == "first_level_threads") p.first_level_threads = to_int(v, key);
+      else if (f == "second_level_threads") p.second_level_threads = to_int(v, key);
+      else if (f == "use_antialiasing") p.use_antialiasing = to_int(v, key);
+      // extension keys (not in the reference's proto)
+      else if (f == "width") p.width = to_int(v, key);
+      else if (f == "height") p.height = to_int(v, key);
+      else if (f == "num_objects") p.num_objects = to_int(v, key);
+      else if (f == "seed") p.seed = to_int(v, key);
+      else if (f == "sampler") p.sampler = (v.text == "counter") ? OFDG_SAMPLER_COUNTER : OFDG_SAMPLER_REF;
+      else throw std::runtime_error("prototxt: unknown data_generation_param field '" + f + "'");
+    }
+    // other fields (bottom, include, data_param.verbose ...) are accepted and ignored
+  }
+}
+}  // namespace
+
+LayerConfig parse_layer_prototxt(const std::string& text) {
+  LayerConfig cfg;
+  ofdg_default_params(&cfg.params);
+  Lexer lx(text);
+  parse_message(lx, "", &cfg, true);
+  return cfg;
+}
+
+// ---------------------------------------------------------------------------
+// texture collection
+// ---------------------------------------------------------------------------
+namespace {
+bool read_ppm(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w, int* h) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) return false;
+  std::string magic;
+  f >> magic;
+  if (magic != "P6") return false;
+  auto next_int = [&](int* out) {
+    for (;;) {
+      int c = f.peek();
+      if (c == '#') { std::string line; std::getline(f, line); continue; }
+      if (std::isspace(c)) { f.get(); continue; }
+      break;
+    }
+    f >> *out;
+    return !f.fail();
+  };
+  int maxv = 0;
+  if (!next_int(w) || !next_int(h) || !next_int(&maxv) || maxv != 255 || *w <= 0 || *h <= 0) return false;
+  f.get();  // single whitespace after maxval
+  std::vector<uint8_t> rgb((size_t)*w * *h * 3);
+  f.read((char*)rgb.data(), (std::streamsize)rgb.size());
+  if ((size_t)f.gcount() != rgb.size()) return false;
+  const size_t n = (size_t)*w * *h;
+  planar_bgr->resize(3 * n);
+  for (size_t i = 0; i < n; ++i) {  // CImg planar R,G,B then swap(c0, c2) (DataGenerator.cpp:129-131)
+    (*planar_bgr)[i] = rgb[3 * i + 2];
+    (*planar_bgr)[n + i] = rgb[3 * i + 1];
+    (*planar_bgr)[2 * n + i] = rgb[3 * i + 0];
+  }
+  return true;
+}
+}  // namespace
+
+void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
+  if (spec.compare(0, 10, "synthetic:") == 0) {
+    int n = 0, w = 0, h = 0;
+    unsigned seed = 0;
+    if (std::sscanf(spec.c_str(), "synthetic:%d:%d:%d:%u", &n, &w, &h, &seed) < 3)
+      throw std::runtime_error("Could not open texture collection (bad synthetic spec)");
+    if (ofdg_pool_synthetic(ctx, n, w, h, seed) != OFDG_OK)
+      throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
+    return;
+  }
+  std::ifstream infile(spec);
+  if (infile.bad() || !infile.is_open()) throw std::runtime_error("Could not open texture collection");  // DataGenerator.cpp:121
+  std::vector<std::string> paths;
+  std::string imagepath;
+  while (!infile.eof()) {  // reference loop: a last line without '\n' is dropped (DataGenerator.cpp:124-126)
+    std::getline(infile, imagepath);
+    if (infile.eof()) break;
+    paths.push_back(imagepath);
+  }
+  if (paths.empty()) throw std::runtime_error("Could not open texture collection (no images listed)");
+  int pw = 0, ph = 0;
+  for (size_t i = 0; i < paths.size(); ++i) {
+    std::vector<uint8_t> img;
+    int w = 0, h = 0;
+    if (!read_ppm(paths[i], &img, &w, &h)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + " as binary PPM)");
+    if (i == 0) {
+      pw = w; ph = h;
+      if (ofdg_pool_alloc(ctx, (int)paths.size(), w, h) != OFDG_OK)
+        throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
+    } else if (w != pw || h != ph) {
+      throw std::runtime_error("Could not open texture collection (all pool images must share one size)");
+    }
+    if (ofdg_pool_upload(ctx, (int)i, img.data(), w, h) != OFDG_OK)
+      throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// DataGenerationLayer
+// ---------------------------------------------------------------------------
+DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt) : cfg_(parse_layer_prototxt(layer_prototxt)) {
+  if (!cfg_.type.empty() && cfg_.type != "DataGeneration") throw std::runtime_error("layer type is not \"DataGeneration\"");
+  int rc = ofdg_create(&cfg_.params, &ctx_);
+  if (rc == OFDG_EBADMODE) throw std::runtime_error("BAD MODE");  // DataGenerator.cpp:2004
+  if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_last_error(nullptr));
+  try {
+    load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+  } catch (...) {
+    ofdg_destroy(ctx_);
+    ctx_ = nullptr;
+    throw;
+  }
+}
+
+DataGenerationLayer::~DataGenerationLayer() { ofdg_destroy(ctx_); }
+
+void DataGenerationLayer::LayerSetUp(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top) {
+  if (!bottom.empty()) throw std::runtime_error("DataGeneration takes no bottom blobs");  // ExactNumBottomBlobs() == 0
+  if (top.size() != 3) throw std::runtime_error("DataGeneration produces exactly 3 top blobs");  // load_batch indexes output[0..2]
+  const int N = cfg_.params.batch_size, H = cfg_.params.height, W = cfg_.params.width;
+  top[0]->Reshape({N, 3, H, W});  // data_generation_layer.cpp:128-130
+  top[1]->Reshape({N, 3, H, W});
+  top[2]->Reshape({N, 2, H, W});
+}
+
+void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top) {
+  (void)bottom;
+  if (top.size() != 3) throw std::runtime_error("DataGeneration produces exactly 3 top blobs");
+  const int N = cfg_.params.batch_size, H = cfg_.params.height, W = cfg_.params.width;
+  top[0]->Reshape({N, 3, H, W});
+  top[1]->Reshape({N, 3, H, W});
+  top[2]->Reshape({N, 2, H, W});
+  int rc = ofdg_forward(ctx_, top[0]->mutable_gpu_data(), top[1]->mutable_gpu_data(), top[2]->mutable_gpu_data(), nullptr);
+  if (rc == OFDG_OK) rc = ofdg_synchronize(ctx_, nullptr);
+  if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+}
+
+void DataGenerationLayer::Forward_cpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top) {
+  Forward_gpu(bottom, top);
+}
+
+}  // namespace ofdg
+
+// ---------------------------------------------------------------------------
+// C-ABI wrappers of the host-side pieces (declared in include/ofdg.h)
+// ---------------------------------------------------------------------------
+using namespace ofdg;
+
+struct ofdg_host_sampler {
+  RefSampler s;
+  ofdg_host_sampler(int m, int w, int h, int n) : s(m, w, h, n) {}
+};
+struct ofdg_layer {
+  std::unique_ptr<DataGenerationLayer> layer;
+  Blob top[3];
+  std::string err;
+};
+static thread_local std::string g_host_error;
+
+extern "C" {
+
+const char* ofdg_host_last_error(void) { return g_host_error.c_str(); }
+
+int ofdg_host_sampler_create(int mode, int width, int height, int num_objects, ofdg_host_sampler** out) {
+  if (!out) return OFDG_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<ofdg_host_sampler> s(new ofdg_host_sampler(mode, width, height, num_objects));
+  if (!s->s.ok()) { g_host_error = "BAD MODE"; return OFDG_EBADMODE; }
+  *out = s.release();
+  return OFDG_OK;
+}
+void ofdg_host_sampler_destroy(ofdg_host_sampler* s) { delete s; }
+int ofdg_host_sampler_next(ofdg_host_sampler* s, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps, int cap, int* n_bps) {
+  if (!s || !tasks || !bps || !n_bps) return OFDG_EINVAL;
+  std::vector<ofdg_blueprint> pool;
+  for (int i = 0; i < n_tasks; ++i) {
+    int rc = s->s.next_task(&pool, &tasks[i], &g_host_error);
+    if (rc != OFDG_OK) return rc;
+  }
+  *n_bps = (int)pool.size();
+  if ((int)pool.size() > cap) { g_host_error = "blueprint capacity exceeded"; return OFDG_ECAPACITY; }
+  std::memcpy(bps, pool.data(), pool.size() * sizeof(ofdg_blueprint));
+  return OFDG_OK;
+}
+
+int ofdg_host_realize(const ofdg_params* prm, int pool_n, int pool_w, int pool_h, const ofdg_task* tasks, int n_tasks,
+                      const ofdg_blueprint* bps, int n_bps, double* shape_mats, int shape_cap, int* n_shapes,
+                      double* object_mats, int object_cap, int* n_objects) {
+  if (!prm || !tasks || !bps || !n_shapes || !n_objects) return OFDG_EINVAL;
+  RealizeConfig cfg{prm->width, prm->height, prm->mode, pool_n, pool_w, pool_h};
+  RealizedBatch b;
+  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &b, &g_host_error);
+  if (rc != OFDG_OK) return rc;
+  *n_shapes = (int)b.shapes.size();
+  *n_objects = (int)b.objects.size();
+  if ((int)b.shapes.size() > shape_cap || (int)b.objects.size() > object_cap) { g_host_error = "capacity"; return OFDG_ECAPACITY; }
+  for (size_t i = 0; i < b.shapes.size() && shape_mats; ++i) std::memcpy(shape_mats + 12 * i, b.shapes[i].m, sizeof(double) * 12);
+  for (size_t i = 0; i < b.objects.size() && object_mats; ++i) {
+    std::memcpy(object_mats + 12 * i, &b.objects[i].motion, sizeof(double) * 6);
+    std::memcpy(object_mats + 12 * i + 6, &b.objects[i].tex_inv, sizeof(double) * 6);
+  }
+  return OFDG_OK;
+}
+
+int ofdg_parse_prototxt(const char* text, ofdg_params* out, char* texture_dbases, int cap, int* n_top) {
+  if (!text || !out) return OFDG_EINVAL;
+  try {
+    LayerConfig cfg = parse_layer_prototxt(text);
+    *out = cfg.params;
+    if (texture_dbases && cap > 0) {
+      std::strncpy(texture_dbases, cfg.texture_dbases.c_str(), (size_t)cap - 1);
+      texture_dbases[cap - 1] = 0;
+    }
+    if (n_top) *n_top = (int)cfg.top.size();
+    return OFDG_OK;
+  } catch (const std::exception& e) {
+    g_host_error = e.what();
+    return OFDG_EINVAL;
+  }
+}
+
+int ofdg_layer_create(const char* prototxt, ofdg_layer** out) {
+  if (!prototxt || !out) return OFDG_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<ofdg_layer> L(new ofdg_layer());
+  try {
+    L->layer.reset(new DataGenerationLayer(prototxt));
+    std::vector<Blob*> top = {&L->top[0], &L->top[1], &L->top[2]};
+    L->layer->LayerSetUp({}, top);
+  } catch (const std::exception& e) {
+    g_host_error = e.what();
+    if (g_host_error == "BAD MODE") return OFDG_EBADMODE;
+    if (g_host_error.find("texture collection") != std::string::npos) return OFDG_ETEXTURES;
+    return OFDG_EINVAL;
+  }
+  *out = L.release();
+  return OFDG_OK;
+}
+void ofdg_layer_destroy(ofdg_layer* L) { delete L; }
+// Forward(): fills the three top blobs and returns their device pointers.
+int ofdg_layer_forward(ofdg_layer* L, float** image0, float** image1, float** flow, int* shape4) {
+  if (!L) return OFDG_EINVAL;
+  try {
+    std::vector<Blob*> top = {&L->top[0], &L->top[1], &L->top[2]};
+    L->layer->Forward_gpu({}, top);
+  } catch (const std::exception& e) {
+    g_host_error = e.what();
+    return OFDG_EHIP;
+  }
+  if (image0) *image0 = L->top[0].mutable_gpu_data();
+  if (image1) *image1 = L->top[1].mutable_gpu_data();
+  if (flow) *flow = L->top[2].mutable_gpu_data();
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = L->top[0].shape()[i];
+  return OFDG_OK;
+}
+
+}  // extern "C"

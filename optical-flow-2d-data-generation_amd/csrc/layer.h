@@ -1,0 +1,82 @@
+// C++ host mirror of the reference's Caffe layer surface for this path:
+// caffe::DataGenerationLayer<float> (include/caffe/layers/data_generation_layer.hpp:37-89,
+// src/caffe/layers/data_generation_layer.cpp) -- same method names, blob shapes and
+// error behaviour (std::runtime_error with the reference's messages), constructed
+// from the layer's prototxt text instead of a caffe::LayerParameter (Caffe and
+// protobuf are not part of this build).  Tops live in HBM.
+#pragma once
+#include <stddef.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ofdg.h"
+
+namespace ofdg {
+
+// Minimal stand-in for caffe::Blob<float>: a shape and a device buffer.
+class Blob {
+ public:
+  Blob() {}
+  ~Blob();
+  Blob(const Blob&) = delete;
+  Blob& operator=(const Blob&) = delete;
+  void Reshape(const std::vector<int>& shape);  // (re)allocates device memory
+  const std::vector<int>& shape() const { return shape_; }
+  size_t count() const { return count_; }
+  size_t offset(int n, int c = 0, int h = 0, int w = 0) const;
+  const float* gpu_data() const { return data_; }
+  float* mutable_gpu_data() { return data_; }
+
+ private:
+  std::vector<int> shape_;
+  size_t count_ = 0, capacity_ = 0;
+  float* data_ = nullptr;
+};
+
+// What the prototxt subset parser extracts (src/caffe/proto/caffe.proto:6-12 and
+// the LMB data_param fields used at data_generation_layer.cpp:44, 109-113).
+struct LayerConfig {
+  std::string name, type;
+  std::vector<std::string> top;
+  ofdg_params params;
+  std::string texture_dbases;  // list file, or "synthetic:N:W:H[:seed]"
+};
+
+// Parses one `layer { ... }` block (protobuf text format subset: nested messages,
+// key: value, strings, numbers, true/false, '#' comments).  Throws std::runtime_error.
+LayerConfig parse_layer_prototxt(const std::string& text);
+
+class DataGenerationLayer {
+ public:
+  explicit DataGenerationLayer(const std::string& layer_prototxt);
+  ~DataGenerationLayer();
+
+  void LayerSetUp(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
+  void Reshape(const std::vector<Blob*>&, const std::vector<Blob*>&) {}
+  inline bool ShareInParallel() const { return false; }
+  inline const char* type() const { return "DataGeneration"; }
+  inline int ExactNumBottomBlobs() const { return 0; }
+  inline int MinTopBlobs() const { return 1; }
+
+  // The reference's Forward_gpu defers to Forward_cpu (data_generation_layer.cpp:286-291);
+  // here both produce the batch on the GPU, directly into the top blobs.
+  void Forward_cpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
+  void Forward_gpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
+  void Backward_cpu(const std::vector<Blob*>&, const std::vector<bool>&, const std::vector<Blob*>&) {}
+  void Backward_gpu(const std::vector<Blob*>&, const std::vector<bool>&, const std::vector<Blob*>&) {}
+
+  const LayerConfig& config() const { return cfg_; }
+  ofdg_ctx* context() { return ctx_; }
+
+ private:
+  LayerConfig cfg_;
+  ofdg_ctx* ctx_ = nullptr;
+};
+
+// Texture list loader: TextureCollection (DataGenerator.cpp:117-149) for binary PPM
+// (P6) files, or a synthetic pool.  Throws std::runtime_error("Could not open texture
+// collection") like the reference.
+void load_texture_collection(ofdg_ctx* ctx, const std::string& spec);
+
+}  // namespace ofdg

@@ -1,0 +1,468 @@
+// C-ABI of the MI355X-native optical-flow data generator (include/ofdg.h).
+// Owns the HIP context state (texture pool, workspaces) and launches the kernels
+// in kernels.hip.  There is no CPU fallback: without a HIP device every entry
+// point that would render fails with OFDG_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ofdg.h"
+#include "kernels.hip"
+#include "ofdg_device.h"
+#include "realize.h"
+#include "sampler_ref.h"
+
+using namespace ofdg;
+
+static thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = n + n / 4 + 16;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ofdg_ctx {
+  ofdg_params prm;
+  std::string err;
+  // texture pool
+  uint32_t* pool = nullptr;
+  int pool_n = 0, pool_w = 0, pool_h = 0;
+  // sampler
+  std::unique_ptr<RefSampler> sampler;
+  long long step = 0;
+  // host staging (pinned) + device records
+  RealizedBatch batch;
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  hipEvent_t stage_free = nullptr;
+  bool stage_pending = false;
+  DevBuf<DevShape> d_shapes;
+  DevBuf<DevShapeFrame> d_frames;
+  DevBuf<int2> d_verts;
+  DevBuf<uint8_t> d_cov;
+  DevBuf<DevObject> d_objects;
+  DevBuf<DevSample> d_samples;
+  double* d_cs_tab = nullptr;
+  uint32_t* d_err = nullptr;
+  // resident batch
+  int res_samples = 0, res_shapes = 0;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  std::vector<ofdg_task> fw_tasks;
+  std::vector<ofdg_blueprint> fw_bps;
+};
+
+#define HIP_OK(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return OFDG_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+extern "C" {
+
+void ofdg_default_params(ofdg_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->width = 512;               // DGEN_WIDTH
+  p->height = 384;              // DGEN_HEIGHT
+  p->mode = 1;                  // caffe.proto:7
+  p->use_antialiasing = 1;      // caffe.proto:11
+  p->batch_size = 1;
+  p->prefetch = 1;
+  p->first_level_threads = 16;  // caffe.proto:9
+  p->second_level_threads = 1;  // caffe.proto:10
+  p->sampler = OFDG_SAMPLER_REF;
+  p->world_size = 1;
+}
+
+const char* ofdg_last_error(const ofdg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
+  if (!params || !out) { g_create_error = "null argument"; return OFDG_EINVAL; }
+  *out = nullptr;
+  if (params->mode < 1 || params->mode > 13) { g_create_error = "BAD MODE"; return OFDG_EBADMODE; }
+  if (params->width < 8 || params->height < 2 || (params->width % 8) != 0 || (params->height % 2) != 0) {
+    g_create_error = "width must be a multiple of 8 and height even";
+    return OFDG_EINVAL;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device available (the HIP kernels are the only render path)";
+    return OFDG_EHIP;
+  }
+  e = hipSetDevice(params->device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return OFDG_EHIP; }
+  std::unique_ptr<ofdg_ctx> c(new ofdg_ctx());
+  c->prm = *params;
+  if (c->prm.world_size < 1) c->prm.world_size = 1;
+  c->sampler.reset(new RefSampler(params->mode, params->width, params->height, params->num_objects));
+  if (!c->sampler->ok()) { g_create_error = "BAD MODE"; return OFDG_EBADMODE; }
+  // cos/sin of agg::ellipse's 100 step angles, from the host libm
+  double tab[200];
+  const double pi = 3.14159265358979323846;
+  for (int step = 0; step < 100; ++step) {
+    const double angle = double(step) / double(100) * 2.0 * pi;
+    tab[2 * step] = std::cos(angle);
+    tab[2 * step + 1] = std::sin(angle);
+  }
+  if ((e = hipMalloc((void**)&c->d_cs_tab, sizeof(tab))) != hipSuccess ||
+      (e = hipMemcpy(c->d_cs_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_err, sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming)) != hipSuccess) {
+    g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
+    return OFDG_EHIP;
+  }
+  for (int i = 0; i < 4; ++i)
+    if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { g_create_error = hipGetErrorString(e); return OFDG_EHIP; }
+  // the raster kernel's cell arrays may exceed the default 64 KiB of dynamic LDS
+  const int lds = 2 * kBandRows * (params->width + 1) * (int)sizeof(int);
+  e = hipFuncSetAttribute((const void*)raster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) {
+    g_create_error = std::string("raster_kernel LDS attribute (is the gfx950 code object present?): ") + hipGetErrorString(e);
+    return OFDG_EHIP;
+  }
+  *out = c.release();
+  return OFDG_OK;
+}
+
+void ofdg_destroy(ofdg_ctx* c) {
+  if (!c) return;
+  (void)hipDeviceSynchronize();
+  if (c->pool) (void)hipFree(c->pool);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  c->d_shapes.release(); c->d_frames.release(); c->d_verts.release(); c->d_cov.release();
+  c->d_objects.release(); c->d_samples.release();
+  if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
+  if (c->d_err) (void)hipFree(c->d_err);
+  if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+  for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+}
+
+// ---- texture pool -------------------------------------------------------------------
+static int pool_check_dims(ofdg_ctx* c, int n, int w, int h) {
+  const int W = c->prm.width, H = c->prm.height;
+  if (n < 1) { c->err = "texture pool needs at least one image"; return OFDG_ETEXTURES; }
+  if (w < 2 * W || h < 2 * H) {
+    // the reference resizes smaller images (DataGenerator.cpp:104-108); not supported yet
+    c->err = "pool images must be at least 2W x 2H (the background's centre crop)";
+    return OFDG_ETEXTURES;
+  }
+  if ((w % 4) != 0 || ((w / 2 - W / 2) % 4) != 0) {
+    c->err = "pool image width and crop origin must be multiples of 4 texels (16-byte texture rows)";
+    return OFDG_ETEXTURES;
+  }
+  return OFDG_OK;
+}
+
+int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
+  if (!c) return OFDG_EINVAL;
+  int rc = pool_check_dims(c, n, w, h);
+  if (rc != OFDG_OK) return rc;
+  HIP_OK(c, hipDeviceSynchronize());
+  if (c->pool) { HIP_OK(c, hipFree(c->pool)); c->pool = nullptr; }
+  HIP_OK(c, hipMalloc((void**)&c->pool, (size_t)n * w * h * sizeof(uint32_t)));
+  HIP_OK(c, hipMemset(c->pool, 0, (size_t)n * w * h * sizeof(uint32_t)));
+  c->pool_n = n; c->pool_w = w; c->pool_h = h;
+  return OFDG_OK;
+}
+
+int ofdg_pool_synthetic(ofdg_ctx* c, int n, int w, int h, uint32_t seed) {
+  int rc = ofdg_pool_alloc(c, n, w, h);
+  if (rc != OFDG_OK) return rc;
+  hipLaunchKernelGGL(pool_synth_kernel, dim3(256 * 8), dim3(256), 0, 0, c->pool, n, w, h, seed);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipDeviceSynchronize());
+  return OFDG_OK;
+}
+
+int ofdg_pool_upload(ofdg_ctx* c, int index, const uint8_t* bgr_planar, int w, int h) {
+  if (!c || !bgr_planar) return OFDG_EINVAL;
+  if (!c->pool || index < 0 || index >= c->pool_n || w != c->pool_w || h != c->pool_h) {
+    c->err = "pool_upload: index / size does not match the allocated pool";
+    return OFDG_ETEXTURES;
+  }
+  uint8_t* tmp = nullptr;
+  const size_t n = (size_t)w * h;
+  HIP_OK(c, hipMalloc((void**)&tmp, 3 * n));
+  HIP_OK(c, hipMemcpy(tmp, bgr_planar, 3 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pool_pack_kernel, dim3(1024), dim3(256), 0, 0, tmp, c->pool + (size_t)index * n, w, h);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, hipFree(tmp));
+  return OFDG_OK;
+}
+
+int ofdg_pool_download(ofdg_ctx* c, int index, uint8_t* bgr_planar) {
+  if (!c || !bgr_planar) return OFDG_EINVAL;
+  if (!c->pool || index < 0 || index >= c->pool_n) { c->err = "pool_download: bad index"; return OFDG_ETEXTURES; }
+  uint8_t* tmp = nullptr;
+  const size_t n = (size_t)c->pool_w * c->pool_h;
+  HIP_OK(c, hipMalloc((void**)&tmp, 3 * n));
+  hipLaunchKernelGGL(pool_unpack_kernel, dim3(1024), dim3(256), 0, 0, c->pool + (size_t)index * n, tmp, c->pool_w, c->pool_h);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipMemcpy(bgr_planar, tmp, 3 * n, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipFree(tmp));
+  return OFDG_OK;
+}
+
+int ofdg_pool_info(const ofdg_ctx* c, int* n, int* w, int* h) {
+  if (!c) return OFDG_EINVAL;
+  if (n) *n = c->pool_n;
+  if (w) *w = c->pool_w;
+  if (h) *h = c->pool_h;
+  return OFDG_OK;
+}
+
+// ---- sampler ---------------------------------------------------------------------------
+int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps, int bps_capacity, int* n_bps) {
+  if (!c || !tasks || !bps || !n_bps || n_tasks < 0) return OFDG_EINVAL;
+  if (c->prm.sampler != OFDG_SAMPLER_REF) { c->err = "only OFDG_SAMPLER_REF is implemented on the host"; return OFDG_EINVAL; }
+  std::vector<ofdg_blueprint> pool;
+  for (int i = 0; i < n_tasks; ++i) {
+    int rc = c->sampler->next_task(&pool, &tasks[i], &c->err);
+    if (rc != OFDG_OK) return rc;
+  }
+  *n_bps = (int)pool.size();
+  if ((int)pool.size() > bps_capacity) { c->err = "blueprint capacity exceeded"; return OFDG_ECAPACITY; }
+  std::memcpy(bps, pool.data(), pool.size() * sizeof(ofdg_blueprint));
+  return OFDG_OK;
+}
+
+// ---- render -------------------------------------------------------------------------------
+static int launch_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
+  const int W = c->prm.width, H = c->prm.height;
+  const int n_sf = c->res_shapes * 2;
+  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[0], st));
+  if (n_sf > 0) {
+    hipLaunchKernelGGL(geom_kernel, dim3(n_sf), dim3(128), 0, st, c->d_shapes.p, c->res_shapes, c->d_cs_tab, W, H,
+                       c->d_frames.p, c->d_verts.p, c->d_err);
+    HIP_OK(c, hipGetLastError());
+  }
+  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[1], st));
+  if (n_sf > 0) {
+    const int bands = (H + kBandRows - 1) / kBandRows;
+    const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
+    hipLaunchKernelGGL(raster_kernel, dim3(n_sf, bands), dim3(256), lds, st, c->d_frames.p, n_sf, c->d_verts.p, W, H,
+                       c->d_cov.p);
+    HIP_OK(c, hipGetLastError());
+  }
+  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[2], st));
+  RenderDims dm;
+  dm.W = W; dm.H = H; dm.pool_w = c->pool_w; dm.pool_h = c->pool_h;
+  dm.use_aa = c->prm.use_antialiasing ? 1 : 0;
+  dm.n_samples = c->res_samples;
+  dm.n_shapes = c->res_shapes;
+  dm.tiles_x = (W + kTileW - 1) / kTileW;
+  dm.tiles_y = (H + kTileH - 1) / kTileH;
+  hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, c->d_samples.p,
+                     c->d_objects.p, c->d_frames.p, c->d_cov.p, c->pool, d_img0, d_img1, d_flow);
+  HIP_OK(c, hipGetLastError());
+  if (c->profiling) { HIP_OK(c, hipEventRecord(c->ev[3], st)); c->ev_valid = true; }
+  return OFDG_OK;
+}
+
+int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
+                float* d_img0, float* d_img1, float* d_flow, void* stream) {
+  if (!c || !tasks || !bps || n_tasks < 1 || !d_img0 || !d_img1 || !d_flow) {
+    if (c) c->err = "ofdg_render: invalid argument";
+    return OFDG_EINVAL;
+  }
+  if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
+  hipStream_t st = (hipStream_t)stream;
+  RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h};
+  // the previous call's host->device copies must have left the staging buffer
+  if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
+  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &c->batch, &c->err);
+  if (rc != OFDG_OK) return rc;
+  const RealizedBatch& B = c->batch;
+  const size_t n_shapes = B.shapes.size(), n_obj = B.objects.size();
+  const int W = c->prm.width, H = c->prm.height;
+  HIP_OK(c, c->d_shapes.reserve(n_shapes));
+  HIP_OK(c, c->d_frames.reserve(n_shapes * 2));
+  HIP_OK(c, c->d_verts.reserve(n_shapes * 2 * kMaxVerts));
+  HIP_OK(c, c->d_cov.reserve(n_shapes * 2 * (size_t)W * H + 16));
+  HIP_OK(c, c->d_objects.reserve(n_obj));
+  HIP_OK(c, c->d_samples.reserve(n_tasks));
+  const size_t b_shapes = n_shapes * sizeof(DevShape), b_obj = n_obj * sizeof(DevObject),
+               b_smp = (size_t)n_tasks * sizeof(DevSample);
+  const size_t need = b_shapes + b_obj + b_smp + 64;
+  if (need > c->h_stage_bytes) {
+    if (c->h_stage) HIP_OK(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    HIP_OK(c, hipHostMalloc(&c->h_stage, need * 2, hipHostMallocDefault));
+    c->h_stage_bytes = need * 2;
+  }
+  char* hs = (char*)c->h_stage;
+  if (b_shapes) std::memcpy(hs, B.shapes.data(), b_shapes);
+  std::memcpy(hs + b_shapes, B.objects.data(), b_obj);
+  std::memcpy(hs + b_shapes + b_obj, B.samples.data(), b_smp);
+  if (b_shapes) HIP_OK(c, hipMemcpyAsync(c->d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemcpyAsync(c->d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemcpyAsync(c->d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipEventRecord(c->stage_free, st));
+  c->stage_pending = true;
+  c->res_samples = n_tasks;
+  c->res_shapes = (int)n_shapes;
+  return launch_resident(c, d_img0, d_img1, d_flow, st);
+}
+
+int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
+  if (!c || !d_img0 || !d_img1 || !d_flow) return OFDG_EINVAL;
+  if (c->res_samples <= 0) { c->err = "ofdg_render_resident: no batch is resident"; return OFDG_EINVAL; }
+  return launch_resident(c, d_img0, d_img1, d_flow, (hipStream_t)stream);
+}
+
+int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
+  if (!c) return OFDG_EINVAL;
+  const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
+  if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
+  // every rank walks the identical sequential stream and keeps its own block of
+  // B consecutive tasks out of each B*world (disjoint shards, no communication)
+  c->fw_bps.clear();
+  c->fw_tasks.assign((size_t)B * world, ofdg_task());
+  for (int i = 0; i < B * world; ++i) {
+    int rc = c->sampler->next_task(&c->fw_bps, &c->fw_tasks[i], &c->err);
+    if (rc != OFDG_OK) return rc;
+  }
+  c->step++;
+  return ofdg_render(c, c->fw_tasks.data() + (size_t)rank * B, B, c->fw_bps.data(), (int)c->fw_bps.size(), d_img0, d_img1,
+                     d_flow, stream);
+}
+
+int ofdg_synchronize(ofdg_ctx* c, void* stream) {
+  if (!c) return OFDG_EINVAL;
+  HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
+  uint32_t e = 0;
+  HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
+  if (e) {
+    HIP_OK(c, hipMemset(c->d_err, 0, sizeof(uint32_t)));
+    c->err = "device capacity exceeded:";
+    if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
+    if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
+    if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
+    return OFDG_ECAPACITY;
+  }
+  return OFDG_OK;
+}
+
+// ---- inspection ---------------------------------------------------------------------------------
+static inline int iround_h(double v) { return int((v < 0.0) ? v - 0.5 : v + 0.5); }
+
+int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage_host) {
+  if (!c || !xy || !coverage_host || n < 1 || n > kMaxVerts) return OFDG_EINVAL;
+  const int W = c->prm.width, H = c->prm.height;
+  std::vector<int2> v(kMaxVerts);
+  int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -0x7fffffff - 1, maxy = -0x7fffffff - 1;
+  for (int i = 0; i < n; ++i) {
+    v[i] = make_int2(iround_h(xy[2 * i] * 256.0), iround_h(xy[2 * i + 1] * 256.0));
+    minx = std::min(minx, v[i].x); maxx = std::max(maxx, v[i].x);
+    miny = std::min(miny, v[i].y); maxy = std::max(maxy, v[i].y);
+  }
+  DevShapeFrame f = DevShapeFrame();
+  f.n_verts = n;
+  int x0 = minx >> 8, y0 = miny >> 8, x1 = maxx >> 8, y1 = maxy >> 8;
+  if (n < 2 || x1 < 0 || y1 < 0 || x0 > W - 1 || y0 > H - 1) { x0 = 1; x1 = 0; y0 = 1; y1 = 0; }
+  else { x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, W - 1); y1 = std::min(y1, H - 1); }
+  f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, c->d_frames.reserve(2));
+  HIP_OK(c, c->d_verts.reserve(2 * kMaxVerts));
+  HIP_OK(c, c->d_cov.reserve((size_t)2 * W * H + 16));
+  HIP_OK(c, hipMemcpy(c->d_frames.p, &f, sizeof(f), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(c->d_verts.p, v.data(), sizeof(int2) * kMaxVerts, hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemset(c->d_cov.p, 0xAB, (size_t)W * H));  // poison: only the bbox may be read back
+  const int bands = (H + kBandRows - 1) / kBandRows;
+  const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
+  hipLaunchKernelGGL(raster_kernel, dim3(1, bands), dim3(256), lds, 0, c->d_frames.p, 1, c->d_verts.p, W, H, c->d_cov.p);
+  HIP_OK(c, hipGetLastError());
+  std::vector<uint8_t> tmp((size_t)W * H);
+  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p, tmp.size(), hipMemcpyDeviceToHost));
+  std::memset(coverage_host, 0, tmp.size());
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
+  c->res_samples = 0;  // the workspaces no longer hold a rendered batch
+  return OFDG_OK;
+}
+
+int ofdg_debug_num_shapes(ofdg_ctx* c, int sample) {
+  if (!c || sample < 0 || sample >= (int)c->batch.samples.size() || c->res_samples <= 0) return OFDG_EINVAL;
+  return c->batch.samples[sample].n_shapes;
+}
+
+int ofdg_debug_coverage(ofdg_ctx* c, int sample, int shape, int frame, uint8_t* coverage_host) {
+  if (!c || !coverage_host || frame < 0 || frame > 1 || c->res_samples <= 0) return OFDG_EINVAL;
+  if (sample < 0 || sample >= (int)c->batch.samples.size()) return OFDG_EINVAL;
+  const DevSample& s = c->batch.samples[sample];
+  if (shape < 0 || shape >= s.n_shapes) return OFDG_EINVAL;
+  const int W = c->prm.width, H = c->prm.height;
+  const size_t sf = (size_t)(s.first_shape + shape) * 2 + frame;
+  HIP_OK(c, hipDeviceSynchronize());
+  DevShapeFrame f;
+  HIP_OK(c, hipMemcpy(&f, c->d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
+  std::vector<uint8_t> tmp((size_t)W * H);
+  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
+  std::memset(coverage_host, 0, tmp.size());
+  for (int y = f.y0; y <= f.y1; ++y)
+    for (int x = f.x0; x <= f.x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
+  return OFDG_OK;
+}
+
+int ofdg_set_profiling(ofdg_ctx* c, int enabled) {
+  if (!c) return OFDG_EINVAL;
+  c->profiling = enabled != 0;
+  c->ev_valid = false;
+  return OFDG_OK;
+}
+
+int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
+  if (!c || !kernel || !ms) return OFDG_EINVAL;
+  if (!c->ev_valid) { c->err = "no profiled render yet (ofdg_set_profiling)"; return OFDG_EINVAL; }
+  int i = -1;
+  if (!std::strcmp(kernel, "geom")) i = 0;
+  else if (!std::strcmp(kernel, "raster")) i = 1;
+  else if (!std::strcmp(kernel, "compose")) i = 2;
+  if (i < 0) { c->err = "unknown kernel name"; return OFDG_EINVAL; }
+  HIP_OK(c, hipEventSynchronize(c->ev[3]));
+  HIP_OK(c, hipEventElapsedTime(ms, c->ev[i], c->ev[i + 1]));
+  return OFDG_OK;
+}
+
+// Exhaustive device tables of the per-byte formulas (tests): add/sub [256*256],
+// aa [256], blend(d, s_fixed, m) [256*256] indexed d*256+m.
+int ofdg_debug_tables(ofdg_ctx* c, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl, uint8_t* blend_tbl, int s_fixed) {
+  if (!c) return OFDG_EINVAL;
+  uint8_t* d = nullptr;
+  HIP_OK(c, hipMalloc((void**)&d, 3 * 65536 + 256));
+  hipLaunchKernelGGL(tables_kernel, dim3(256), dim3(256), 0, 0, d, d + 65536, d + 3 * 65536, d + 2 * 65536, s_fixed);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipMemcpy(add_tbl, d, 65536, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(sub_tbl, d + 65536, 65536, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(blend_tbl, d + 2 * 65536, 65536, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(aa_tbl, d + 3 * 65536, 256, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipFree(d));
+  return OFDG_OK;
+}
+
+}  // extern "C"

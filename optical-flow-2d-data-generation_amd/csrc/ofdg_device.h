@@ -1,0 +1,79 @@
+// Device-side records of the render pipeline (host realize -> geom -> raster ->
+// compose).  Plain PODs shared by host code and HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace ofdg {
+
+constexpr int kMaxSegments = 20;    // OFDG_MAX_SEGMENTS
+constexpr int kMaxComponents = 8;   // OFDG_MAX_COMPONENTS
+constexpr int kMaxVerts = 1024;     // flattened outline capacity per (shape, frame)
+constexpr int kCurveMaxPts = 96;    // points one curve3 may flatten to
+constexpr int kCurveMaxDepth = 16;  // DFS stack depth for curve3 subdivision
+constexpr int kBandRows = 8;        // scanlines one raster workgroup accumulates in LDS
+
+// error bits raised by kernels (device word, read by ofdg_synchronize)
+constexpr uint32_t kErrVertCapacity = 1u;   // outline has more than kMaxVerts vertices
+constexpr uint32_t kErrCurveCapacity = 2u;  // a curve exceeded kCurveMaxPts / kCurveMaxDepth
+constexpr uint32_t kErrDxLimit = 4u;        // an edge spans >= 16384 px (AGG dx_limit)
+
+// 2x3 affine in AGG's member order (sx, shy, shx, sy, tx, ty), fp64.
+struct Mat {
+  double sx, shy, shx, sy, tx, ty;
+};
+
+// One rasterised outline: an ellipse or polygon blueprint (top-level object or a
+// component of a composite) with its two outline transforms.
+// Reference: MovingObjectEllipse/Polygon::renderMasks, DataGenerator.cpp:465-479, 520-534.
+struct DevShape {
+  Mat m[2];        // frame 0: intrinsic; frame 1: intrinsic * motion
+  float seg_x[kMaxSegments];
+  float seg_y[kMaxSegments];
+  int32_t seg_type[kMaxSegments];
+  float rx, ry;    // ellipse radii
+  int32_t type;    // 1 ellipse, 2 polygon
+  int32_t n_seg;
+  int32_t sample;  // batch slot
+  int32_t deform;  // mode 9: frame-1 mask is re-sampled through warp slot `deform-1`
+  int32_t pad[2];
+};
+
+// Produced by the geom kernel for each (shape, frame).
+struct DevShapeFrame {
+  int32_t n_verts;
+  int32_t x0, y0, x1, y1;  // pixel bbox clipped to the screen, inclusive; empty: x0 > x1
+  int32_t pad[3];
+};
+
+// One blitted object (background or top-level foreground object), in z-order.
+// Reference: RenderCore::blitObject / getPointFlow, DataGenerator.cpp:762-799, 388-407, 692-718.
+struct DevObject {
+  Mat motion;         // m_motion (fg: incl. background motion)
+  Mat tex_inv;        // inverse of the texture warp transform (getTransformedTexture, :203-205)
+  uint64_t tex_base;  // texel offset of the pool image's crop origin
+  int32_t first_shape;
+  int32_t n_shapes;   // 0 background, 1 simple shape, >=1 composite
+  uint32_t additive;  // bit k: component k is additive (composite only)
+  int32_t kind;       // 0 background, 1 simple, 2 composite
+  int32_t id;
+  int32_t deform;     // mode 9: warp slot + 1, 0 = rigid
+  int32_t pad[2];
+};
+
+struct DevSample {
+  int32_t first_object;  // background first, then foreground objects by ascending ID
+  int32_t n_objects;
+  int32_t first_shape;
+  int32_t n_shapes;
+};
+
+struct RenderDims {
+  int32_t W, H;            // output size
+  int32_t pool_w, pool_h;  // pool image size (texels are BGRX u32)
+  int32_t use_aa;
+  int32_t n_samples;
+  int32_t n_shapes;        // total rasterised shapes in the batch
+  int32_t tiles_x, tiles_y;
+};
+
+}  // namespace ofdg

@@ -1,0 +1,159 @@
+#include "realize.h"
+
+namespace ofdg {
+namespace {
+
+struct Motion {
+  Mat intrinsic, motion;
+};
+
+// setIntrinsicTransform + setMotion + addBackgroundMotion (DataGenerator.cpp:302-335)
+Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H) {
+  Motion r;
+  r.intrinsic = mat_identity();
+  r.intrinsic = mat_mul(r.intrinsic, mat_rotation(p.init_rot));
+  r.intrinsic = mat_mul(r.intrinsic, mat_translation(p.init_trans_x, p.init_trans_y));
+  r.motion = mat_identity();
+  r.motion = mat_mul(r.motion, mat_rotation(p.rot));
+  r.motion = mat_mul(r.motion, mat_scaling(p.scale));
+  r.motion = mat_mul(r.motion, mat_translation(p.trans_x, p.trans_y));
+  Mat bg_n = mat_translation(-W / 2., -H / 2.);
+  bg_n = mat_mul(bg_n, bg_motion);
+  bg_n = mat_mul(bg_n, mat_translation(W / 2., H / 2.));
+  r.motion = mat_mul(r.motion, bg_n);
+  return r;
+}
+
+int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample,
+               std::vector<DevShape>* shapes, std::string* msg) {
+  if (p.obj_type != OFDG_OBJ_ELLIPSE && p.obj_type != OFDG_OBJ_POLYGON) {
+    *msg = "(RealizeObjectBlueprint) Bad object type, or not intended in this mode";  // DataGenerator.cpp:1143
+    return OFDG_EOBJTYPE;
+  }
+  DevShape s = DevShape();
+  const Motion m = object_motion(p, bg_motion, cfg.W, cfg.H);
+  s.m[0] = m.intrinsic;
+  s.m[1] = mat_mul(m.intrinsic, m.motion);  // "save = intrinsic; save *= motion" (:469-470, 522-523)
+  s.type = p.obj_type;
+  s.rx = p.ellipse_scale_x;
+  s.ry = p.ellipse_scale_y;
+  s.sample = sample;
+  if (p.obj_type == OFDG_OBJ_POLYGON) {
+    if (p.n_segments < 1 || p.n_segments > kMaxSegments) {
+      *msg = "polygon blueprint with a segment count outside [1, 20]";
+      return OFDG_ECAPACITY;
+    }
+    s.n_seg = p.n_segments;
+    for (int i = 0; i < p.n_segments; ++i) {
+      s.seg_x[i] = p.segment_x[i];
+      s.seg_y[i] = p.segment_y[i];
+      s.seg_type[i] = p.segment_type[i];
+      if (i > 0 && p.segment_type[i] == OFDG_SEG_DUMMY &&
+          !(p.segment_type[i - 1] == OFDG_SEG_CURVE3)) {
+        *msg = "PolySegmentType_t::Dummy found, this should have been skipped!";  // DataGenerator.cpp:1096
+        return OFDG_EOBJTYPE;
+      }
+      if (p.segment_type[i] == OFDG_SEG_CURVE3 && i + 1 >= p.n_segments) {
+        *msg = "Curve3 segment without an end point";
+        return OFDG_EOBJTYPE;
+      }
+    }
+  }
+  shapes->push_back(s);
+  return OFDG_OK;
+}
+
+}  // namespace
+
+int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
+                  int n_bps, RealizedBatch* out, std::string* msg) {
+  out->shapes.clear();
+  out->objects.clear();
+  out->samples.clear();
+  const int W = cfg.W, H = cfg.H;
+  // fg: Texture::getRandomizedCrop() with defaults == exact centre W x H crop
+  // (DataGenerator.cpp:87-109 via :1149-1150); bg: 2W x 2H centre crop (parity boundary:
+  // tex_rot / tex_scale / tex_shift preparation is not applied).
+  const uint64_t img_texels = (uint64_t)cfg.pool_w * cfg.pool_h;
+  const uint64_t fg_origin = (uint64_t)(cfg.pool_h / 2 - H / 2) * cfg.pool_w + (cfg.pool_w / 2 - W / 2);
+  const uint64_t bg_origin = (uint64_t)(cfg.pool_h / 2 - H) * cfg.pool_w + (cfg.pool_w / 2 - W);
+  for (int t = 0; t < n_tasks; ++t) {
+    const ofdg_task& task = tasks[t];
+    if (task.background < 0 || task.background >= n_bps || task.n_objects < 0 ||
+        task.first_object < 0 || task.first_object + task.n_objects > n_bps) {
+      *msg = "task refers to blueprints outside the array";
+      return OFDG_EINVAL;
+    }
+    DevSample smp;
+    smp.first_object = (int32_t)out->objects.size();
+    smp.first_shape = (int32_t)out->shapes.size();
+    // background (DataGenerator.cpp:1183-1205, 654-663)
+    const ofdg_blueprint& pb = bps[task.background];
+    Mat bg_motion = mat_identity();
+    bg_motion = mat_mul(bg_motion, mat_rotation(pb.rot));
+    bg_motion = mat_mul(bg_motion, mat_scaling(pb.scale));
+    bg_motion = mat_mul(bg_motion, mat_translation(pb.trans_x, pb.trans_y));
+    {
+      DevObject o = DevObject();
+      o.kind = 0;
+      o.id = pb.obj_id;
+      o.motion = bg_motion;
+      // setIntrinsicTransform(0.f, W, H): rotation(0) * translation(W, H)
+      Mat intrinsic = mat_mul(mat_mul(mat_identity(), mat_rotation(0.f)), mat_translation(W, H));
+      Mat intrinsic_inv = mat_invert(intrinsic);
+      // m_intrinsic_transform_inv * m_motion * m_intrinsic_transform (:673, 677), inverted (:203-205)
+      Mat warp = mat_mul(mat_mul(intrinsic_inv, bg_motion), intrinsic);
+      o.tex_inv = mat_invert(warp);
+      o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;
+      o.first_shape = 0;
+      o.n_shapes = 0;
+      out->objects.push_back(o);
+    }
+    // foreground objects; std::map order == ascending obj_id (DataGenerator.cpp:1216-1223)
+    std::vector<int> order(task.n_objects);
+    for (int i = 0; i < task.n_objects; ++i) order[i] = task.first_object + i;
+    for (size_t i = 1; i < order.size(); ++i)  // insertion sort by id (already sorted when sampled)
+      for (size_t j = i; j > 0 && bps[order[j]].obj_id < bps[order[j - 1]].obj_id; --j) std::swap(order[j], order[j - 1]);
+    for (int bi : order) {
+      const ofdg_blueprint& p = bps[bi];
+      if (p.obj_id <= OFDG_BACKGROUND_ID) {
+        *msg = "foreground object id must be > 1 (the background owns id 1)";
+        return OFDG_EINVAL;
+      }
+      DevObject o = DevObject();
+      o.id = p.obj_id;
+      const Motion m = object_motion(p, bg_motion, W, H);
+      o.motion = m.motion;
+      o.tex_inv = mat_invert(m.motion);
+      o.tex_base = (uint64_t)(p.tex_id % cfg.pool_n) * img_texels + fg_origin;
+      o.first_shape = (int32_t)out->shapes.size();
+      if (p.obj_type == OFDG_OBJ_COMPOSITE) {
+        if (p.n_components < 1 || p.n_components > kMaxComponents || p.first_component < 0 ||
+            p.first_component + p.n_components > n_bps) {
+          *msg = "composite blueprint with a component range outside [1, 8] / the array";
+          return OFDG_ECAPACITY;
+        }
+        o.kind = 2;
+        o.n_shapes = p.n_components;
+        for (int k = 0; k < p.n_components; ++k) {
+          const ofdg_blueprint& c = bps[p.first_component + k];
+          int rc = push_shape(cfg, c, bg_motion, t, &out->shapes, msg);
+          if (rc != OFDG_OK) return rc;
+          if (c.is_additive_component) o.additive |= (1u << k);
+        }
+      } else {
+        o.kind = 1;
+        o.n_shapes = 1;
+        int rc = push_shape(cfg, p, bg_motion, t, &out->shapes, msg);
+        if (rc != OFDG_OK) return rc;
+      }
+      out->objects.push_back(o);
+    }
+    smp.n_objects = (int32_t)out->objects.size() - smp.first_object;
+    smp.n_shapes = (int32_t)out->shapes.size() - smp.first_shape;
+    out->samples.push_back(smp);
+  }
+  return OFDG_OK;
+}
+
+}  // namespace ofdg

@@ -1,0 +1,62 @@
+// Host "realize" step: blueprints -> device records (fp64 affines in the
+// reference's operation order, texture placement, z-order).
+//
+// Mirrors DataGenerator::RealizeObjectBlueprint and the object set-up half of
+// Process_TaskBucket (reference src/caffe/DataGenerator.cpp:1065-1173, 1183-1211)
+// and MovingObjectBase::setIntrinsicTransform / setMotion / addBackgroundMotion
+// (:302-335).  The 2x3 algebra restates agg::trans_affine (AGG 2.4
+// agg_trans_affine.h): multiply = "apply this, then m"; members sx,shy,shx,sy,tx,ty.
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/ofdg.h"
+#include "ofdg_device.h"
+
+namespace ofdg {
+
+inline Mat mat_identity() { return Mat{1.0, 0.0, 0.0, 1.0, 0.0, 0.0}; }
+inline Mat mat_rotation(double a) { return Mat{std::cos(a), std::sin(a), -std::sin(a), std::cos(a), 0.0, 0.0}; }
+inline Mat mat_scaling(double s) { return Mat{s, 0.0, 0.0, s, 0.0, 0.0}; }
+inline Mat mat_translation(double x, double y) { return Mat{1.0, 0.0, 0.0, 1.0, x, y}; }
+inline Mat mat_mul(const Mat& a, const Mat& m) {  // a *= m
+  Mat r;
+  r.sx = a.sx * m.sx + a.shy * m.shx;
+  r.shx = a.shx * m.sx + a.sy * m.shx;
+  r.tx = a.tx * m.sx + a.ty * m.shx + m.tx;
+  r.shy = a.sx * m.shy + a.shy * m.sy;
+  r.sy = a.shx * m.shy + a.sy * m.sy;
+  r.ty = a.tx * m.shy + a.ty * m.sy + m.ty;
+  return r;
+}
+inline Mat mat_invert(const Mat& a) {
+  Mat r;
+  const double d = 1.0 / (a.sx * a.sy - a.shy * a.shx);
+  const double t0 = a.sy * d;
+  r.sy = a.sx * d;
+  r.shy = -a.shy * d;
+  r.shx = -a.shx * d;
+  const double t4 = -a.tx * t0 - a.ty * r.shx;
+  r.ty = -a.tx * r.shy - a.ty * r.sy;
+  r.sx = t0;
+  r.tx = t4;
+  return r;
+}
+
+struct RealizedBatch {
+  std::vector<DevShape> shapes;
+  std::vector<DevObject> objects;
+  std::vector<DevSample> samples;
+};
+
+struct RealizeConfig {
+  int W, H, mode;
+  int pool_n, pool_w, pool_h;
+};
+
+// Returns OFDG_OK or an error code; *msg explains failures.
+int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
+                  int n_bps, RealizedBatch* out, std::string* msg);
+
+}  // namespace ofdg

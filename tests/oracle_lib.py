@@ -77,22 +77,22 @@ def lib():
         L.ofdg_oracle_sampler_create.restype = C.c_void_p
         L.ofdg_oracle_sampler_create.argtypes = [C.c_int] * 4
         L.ofdg_oracle_sampler_destroy.argtypes = [C.c_void_p]
-        L.ofdg_oracle_sampler_next.argtypes = [C.c_void_p, C.c_int, C.POINTER(Task), C.POINTER(Blueprint), C.c_int]
+        L.ofdg_oracle_sampler_next.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ofdg_oracle_rng_draws.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.ofdg_oracle_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ofdg_oracle_curve3.argtypes = [C.c_double] * 6 + [C.c_void_p, C.c_int]
-        L.ofdg_oracle_outline.argtypes = [C.POINTER(Blueprint), C.c_void_p, C.c_void_p, C.c_int]
+        L.ofdg_oracle_outline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ofdg_oracle_dda_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ofdg_oracle_transformed_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ofdg_oracle_tables.argtypes = [C.c_void_p] * 3
         L.ofdg_oracle_draw_image_value.restype = C.c_uint8
         L.ofdg_oracle_draw_image_value.argtypes = [C.c_uint8] * 3
         L.ofdg_oracle_flowfield.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.ofdg_oracle_render.argtypes = [C.POINTER(Params), C.POINTER(Task), C.c_int, C.POINTER(Blueprint), C.c_int,
+        L.ofdg_oracle_render.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.ofdg_oracle_shape_masks.argtypes = [C.POINTER(Params), C.POINTER(Task), C.POINTER(Blueprint),
+        L.ofdg_oracle_shape_masks.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -120,7 +120,7 @@ class Sampler:
         cap = cap or n_tasks * 256
         tasks = (Task * n_tasks)()
         bps = (Blueprint * cap)()
-        n = lib().ofdg_oracle_sampler_next(self.h, n_tasks, tasks, bps, cap)
+        n = lib().ofdg_oracle_sampler_next(self.h, n_tasks, C.cast(tasks, C.c_void_p), C.cast(bps, C.c_void_p), cap)
         if n < 0:
             raise RuntimeError("blueprint capacity: need %d" % -n)
         return tasks, bps, n
@@ -200,7 +200,7 @@ def render(params, tasks, n_tasks, bps, n_bps, pool, warp_crops=None, reuse=2, n
         wc, ncrops = _ptr(warp_crops), len(warp_crops)
     else:
         wc, ncrops = None, 0
-    rc = lib().ofdg_oracle_render(C.byref(params), tasks, n_tasks, bps, n_bps, _ptr(pool), pn, pw, ph,
+    rc = lib().ofdg_oracle_render(C.byref(params), C.cast(tasks, C.c_void_p), n_tasks, C.cast(bps, C.c_void_p), n_bps, _ptr(pool), pn, pw, ph,
                                   wc, ncrops, reuse, _ptr(img0), _ptr(img1), _ptr(flow), n_threads)
     if rc != 0:
         raise RuntimeError("oracle render failed: %d" % rc)
@@ -212,7 +212,7 @@ def shape_masks(params, task, bps, pool, max_shapes=64):
     pn, _, ph, pw = pool.shape
     W, H = params.width, params.height
     masks = np.zeros((max_shapes, 4, H, W), np.uint8)
-    n = lib().ofdg_oracle_shape_masks(C.byref(params), C.byref(task), bps, _ptr(pool), pn, pw, ph, _ptr(masks), max_shapes)
+    n = lib().ofdg_oracle_shape_masks(C.byref(params), C.byref(task), C.cast(bps, C.c_void_p), _ptr(pool), pn, pw, ph, _ptr(masks), max_shapes)
     if n < 0:
         raise RuntimeError("oracle shape_masks failed: %d" % n)
     return masks[:min(n, max_shapes)]

@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libofdg.so), against
+the oracle on identical inputs and against the committed AGG golden vectors.
+
+Bars: bit-exact for every integer/byte result (coverage, masks, frames -- the
+north-star allows <= 1 LSB on frames, these tests demand 0); flow within 1 ULP
+(north-star tolerance; with host-computed affines the tests observe 0 ULP).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def agg():
+    return np.load(os.path.join(GOLD, "agg_goldens.npz"))
+
+
+def make_gen(ofdg, W, H, mode, use_aa=1, num_objects=0, pool=(4, None, None), seed=7):
+    p = ofdg.default_params(width=W, height=H, mode=mode, use_antialiasing=use_aa, num_objects=num_objects)
+    g = ofdg.Generator(p)
+    n, pw, ph = pool
+    g.pool_synthetic(n, pw or 2 * W, ph or 2 * H, seed)
+    return g
+
+
+def render_gpu(ofdg, g, tasks, n_tasks, bps, n_bps):
+    torch = torch_mod()
+    W, H = g.params.width, g.params.height
+    i0, i1, fl = ofdg.alloc_outputs(n_tasks, H, W)
+    i0.fill_(-1)
+    i1.fill_(-1)
+    fl.fill_(-12345)
+    g.render(tasks, n_tasks, bps, n_bps, i0, i1, fl)
+    g.synchronize()
+    torch.cuda.synchronize()
+    return i0.cpu().numpy(), i1.cpu().numpy(), fl.cpu().numpy()
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def compare(oracle, params, tasks, n_tasks, bps, n_bps, pool, got, flow_ulp=1):
+    e0, e1, ef = oracle.render(params_for_oracle(oracle, params), tasks, n_tasks, bps, n_bps, pool)
+    g0, g1, gf = got
+    assert np.array_equal(g0, e0), "image0 differs: %d px, max %g" % ((g0 != e0).sum(), np.abs(g0 - e0).max())
+    assert np.array_equal(g1, e1), "image1 differs: %d px, max %g" % ((g1 != e1).sum(), np.abs(g1 - e1).max())
+    d = ulp_diff(gf, ef)
+    assert d.max() <= flow_ulp, "flow differs by up to %d ULP at %d px" % (d.max(), (d > flow_ulp).sum())
+    return d.max()
+
+
+def params_for_oracle(oracle, p):
+    q = oracle.default_params(p.width, p.height, p.mode, p.use_antialiasing, p.batch_size, p.num_objects)
+    return q
+
+
+# ---------------------------------------------------------------------------
+def test_device_byte_formulas_exhaustive(ofdg, oracle):
+    """All 65536 (u, v) pairs of the composite add/subtract formulas (strict fp32),
+    the AA mask byte table, and the draw_image blend for several sprite values."""
+    g = make_gen(ofdg, 64, 48, 7)
+    add_o, sub_o, aa_o = oracle.tables()
+    for s in (0, 1, 128, 200, 255):
+        add_g, sub_g, aa_g, bl_g = g.debug_tables(s)
+        assert np.array_equal(add_g, add_o)
+        assert np.array_equal(sub_g, sub_o)
+        assert np.array_equal(aa_g, aa_o)
+        d = np.arange(256)[:, None]
+        m = np.arange(256)[None, :]
+        assert np.array_equal(bl_g, ((m * s + (255 - m) * d) // 255).astype(np.uint8))
+
+
+def test_rasteriser_matches_agg_goldens(ofdg, agg):
+    """raster_kernel (closed-form cells + LDS atomics + wave scan) vs matplotlib's AGG."""
+    W, H = [int(v) for v in agg["canvas"]]
+    g = make_gen(ofdg, W, H, 5)
+    off = 0
+    for i, n in enumerate(agg["poly_len"]):
+        xy = agg["poly_xy"][off:off + n]
+        off += n
+        cov = g.debug_rasterize(xy)
+        assert np.array_equal(cov, agg["poly_cov"][i]), "polygon %d: %d px differ" % (i, (cov != agg["poly_cov"][i]).sum())
+
+
+def test_rasteriser_offscreen_and_clipped(ofdg, oracle):
+    """Shapes crossing every screen edge, fully outside, larger than the screen, degenerate."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 5)
+    rng = np.random.RandomState(3)
+    cases = []
+    for i in range(150):
+        n = rng.randint(3, 21)
+        phi = (np.arange(n) * 360.0 / n + rng.uniform(-10, 10, n)) * np.pi / 180
+        r = rng.uniform(5, 120, n)
+        cx, cy = rng.uniform(-80, W + 80), rng.uniform(-80, H + 80)
+        cases.append(np.stack([cx + r * np.cos(phi), cy + r * np.sin(phi)], 1))
+    cases.append(np.array([[-500.0, -500], [500, -500], [500, 500], [-500, 500]]))   # covers everything
+    cases.append(np.array([[-50.0, 10], [-10, 10], [-10, 40], [-50, 40]]))          # entirely left
+    cases.append(np.array([[200.0, 10], [300, 10], [300, 40], [200, 40]]))          # entirely right
+    cases.append(np.array([[10.0, -40], [60, -40], [60, -5], [10, -5]]))            # entirely above
+    cases.append(np.array([[10.0, 10], [10, 10], [10, 10]]))                         # degenerate point
+    cases.append(np.array([[10.0, 10], [100, 10], [50, 10]]))                        # zero-area horizontal
+    cases.append(np.array([[10.25, 5], [10.25, 90], [10.75, 90], [10.75, 5]]))      # thinner than a pixel
+    cases.append(np.array([[0.0, 0], [128, 0], [128, 96], [0, 96]]))                 # exactly the screen
+    cases.append(np.array([[-300.0, 48.3], [400, 48.6], [400, 49.1], [-300, 48.9]]))  # long near-horizontal sliver
+    for i, xy in enumerate(cases):
+        cov = g.debug_rasterize(xy)
+        exp = oracle.rasterize(xy, W, H)
+        assert np.array_equal(cov, exp), "case %d: %d px differ" % (i, (cov != exp).sum())
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 5, 7, 13])
+def test_render_matches_oracle_small(ofdg, oracle, mode):
+    """End to end on a 128x96 frame: objects are large relative to the frame, so
+    overlaps, clipping and composites are dense."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, mode, pool=(5, 256, 192))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(mode, W, H)
+    tasks, bps, n = s.next(6)
+    got = render_gpu(ofdg, g, tasks, 6, bps, n)
+    compare(oracle, g.params, tasks, 6, bps, n, pool, got, flow_ulp=0)
+
+
+@pytest.mark.parametrize("mode,use_aa", [(7, 1), (7, 0), (5, 1)])
+def test_render_matches_oracle_full_size(ofdg, oracle, mode, use_aa):
+    """BASELINE configuration size 512x384 (config 1 / 2 shapes), pool images 1024x768."""
+    W, H = 512, 384
+    g = make_gen(ofdg, W, H, mode, use_aa=use_aa, pool=(3, 1024, 768))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(mode, W, H)
+    tasks, bps, n = s.next(2)
+    got = render_gpu(ofdg, g, tasks, 2, bps, n)
+    compare(oracle, g.params, tasks, 2, bps, n, pool, got, flow_ulp=0)
+
+
+def test_config1_single_object(ofdg, oracle):
+    """BASELINE config 1: FlyingChairs default mode, 512x384, batch=1, 1 object, fixed seed."""
+    W, H = 512, 384
+    g = make_gen(ofdg, W, H, 7, num_objects=1, pool=(2, 1024, 768))
+    pool = g.pool_download_all()
+    tasks, bps, n = g.sample(1)           # the product's own reference-stream sampler
+    ot, ob, on = oracle.Sampler(7, W, H, 1).next(1)
+    assert n == on and C.string_at(C.addressof(bps), n * C.sizeof(ofdg.Blueprint)) == C.string_at(C.addressof(ob), n * C.sizeof(oracle.Blueprint))
+    got = render_gpu(ofdg, g, tasks, 1, bps, n)
+    compare(oracle, g.params, ot, 1, ob, on, pool, got, flow_ulp=0)
+
+
+def test_shape_coverage_matches_oracle_masks(ofdg, oracle):
+    """Per-shape raw coverage from the device vs the oracle's four masks per shape."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 7, pool=(3, 256, 192))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(7, W, H)
+    tasks, bps, n = s.next(3)
+    render_gpu(ofdg, g, tasks, 3, bps, n)
+    _, _, aa = oracle.tables()
+    for t in range(3):
+        masks = oracle.shape_masks(params_for_oracle(oracle, g.params), tasks[t], bps, pool, max_shapes=200)
+        assert g.debug_num_shapes(t) == len(masks)
+        for k in range(len(masks)):
+            for fr in range(2):
+                cov = g.debug_coverage(t, k, fr)
+                assert np.array_equal(aa[cov], masks[k][fr]), (t, k, fr)
+                assert np.array_equal(np.where(cov >= 128, 255, 0).astype(np.uint8), masks[k][2 + fr]), (t, k, fr)
+
+
+def test_empty_and_ragged_batches(ofdg, oracle):
+    """A task with zero foreground objects, and tasks with different object counts."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 5, pool=(3, 256, 192))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(5, W, H)
+    tasks, bps, n = s.next(4)
+    tasks[1].n_objects = 0
+    tasks[2].n_objects = 3
+    got = render_gpu(ofdg, g, tasks, 4, bps, n)
+    compare(oracle, g.params, tasks, 4, bps, n, pool, got, flow_ulp=0)
+
+
+def test_errors(ofdg):
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.Generator(ofdg.default_params(mode=14))
+    assert e.value.code == ofdg.EBADMODE
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=5))
+    torch_mod()
+    i0, i1, fl = ofdg.alloc_outputs(1, 96, 128)
+    hs = ofdg.HostSampler(5, 128, 96)
+    tasks, bps, n = hs.next(1)
+    with pytest.raises(ofdg.OfdgError) as e:  # no texture pool yet
+        g.render(tasks, 1, bps, n, i0, i1, fl)
+    assert e.value.code == ofdg.ETEXTURES
+    with pytest.raises(ofdg.OfdgError) as e:  # pool images smaller than 2W x 2H
+        g.pool_synthetic(2, 128, 96, 0)
+    assert e.value.code == ofdg.ETEXTURES
+    g.pool_synthetic(2, 256, 192, 0)
+    bps[tasks[0].first_object].obj_type = 0  # Dummy: "Bad object type"
+    with pytest.raises(ofdg.OfdgError) as e:
+        g.render(tasks, 1, bps, n, i0, i1, fl)
+    assert e.value.code == ofdg.EOBJTYPE
+
+
+def test_full_size_properties(ofdg):
+    """BASELINE config 2 at full size (512x384, batch 32, 16 objects, mode 5):
+    size-independent properties instead of the (slow) oracle."""
+    torch = torch_mod()
+    W, H, B = 512, 384, 32
+    g = make_gen(ofdg, W, H, 5, num_objects=16, pool=(16, 1024, 768))
+    tasks, bps, n = g.sample(B)
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    g.render(tasks, B, bps, n, i0, i1, fl)
+    g.synchronize()
+    a0, a1, af = i0.clone(), i1.clone(), fl.clone()
+    # idempotence: re-rendering the resident batch gives identical bytes
+    i0.zero_(); i1.zero_(); fl.zero_()
+    g.render_resident(i0, i1, fl)
+    g.synchronize()
+    assert torch.equal(a0, i0) and torch.equal(a1, i1) and torch.equal(af, fl)
+    # frames hold integers in [0, 255]
+    for t in (a0, a1):
+        assert float(t.min()) >= 0 and float(t.max()) <= 255 and torch.equal(t, t.round())
+    assert torch.isfinite(af).all()
+    # batch-order independence: sample k rendered alone equals slot k of the batch
+    one0, one1, onef = ofdg.alloc_outputs(1, H, W)
+    k = 17
+    sub = (ofdg.Task * 1)(tasks[k])
+    g.render(sub, 1, bps, n, one0, one1, onef)
+    g.synchronize()
+    assert torch.equal(one0[0], a0[k]) and torch.equal(one1[0], a1[k]) and torch.equal(onef[0], af[k])
+    # a pure-translation background far from any object: flow equals the bg affine
+    # (checked through linearity: second differences of the flow field vanish on bg pixels
+    # of a sample without foreground objects)
+    tasks[0].n_objects = 0
+    g.render(tasks, 1, bps, n, one0, one1, onef)
+    g.synchronize()
+    f = onef[0].double()
+    d2x = f[:, :, 2:] - 2 * f[:, :, 1:-1] + f[:, :, :-2]
+    d2y = f[:, 2:, :] - 2 * f[:, 1:-1, :] + f[:, :-2, :]
+    assert float(d2x.abs().max()) < 1e-4 and float(d2y.abs().max()) < 1e-4

@@ -1,0 +1,176 @@
+"""CPU tests: the parity oracle against its pins.
+
+G2  RNG draws        <- the reference's own SimpleRandom.h compiled here (rng_goldens.json)
+G1  sampler          <- blueprint values recorded from the reference's sampler
+G3  rasteriser       <- matplotlib's compiled AGG coverage (agg_goldens.npz)
+G4  curve3 flattening <- matplotlib's compiled AGG conv_curve
+G5  span interpolator <- matplotlib's compiled AGG via _image.resample(NEAREST)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def agg():
+    return np.load(os.path.join(GOLD, "agg_goldens.npz"))
+
+
+def test_rng_matches_reference_simplerandom(oracle):
+    ref = json.load(open(os.path.join(GOLD, "rng_goldens.json")))
+    for case in ref["uniform_int"]:
+        got = oracle.rng_draws(0, case["seed"], case["a"], case["b"], n=len(case["draws"]))
+        assert [int(v) for v in got] == case["draws"], case
+    for case in ref["uniform_float"]:
+        got = oracle.rng_draws(1, case["seed"], case["a"], case["b"], n=len(case["draws"]))
+        # the JSON holds %.9g of a float32, which round-trips exactly
+        assert [np.float32(v) for v in got] == [np.float32(v) for v in case["draws"]], case
+    for case in ref["normal"]:
+        got = oracle.rng_draws(2, case["seed"], n=len(case["draws"]))
+        assert [np.float32(v) for v in got] == [np.float32(v) for v in case["draws"]], case
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def test_sampler_known_answers(oracle):
+    ka = json.load(open(os.path.join(GOLD, "sampler_known_answers.json")))
+    s = oracle.Sampler(ka["mode"])
+    tasks, bps, n = s.next(2)
+    t0 = tasks[0]
+    bg = bps[t0.background]
+    for k, v in ka["task0"]["bg"].items():
+        got = getattr(bg, k)
+        assert (got == v) if isinstance(v, int) else (_f32(got) == _f32(v)), (k, got, v)
+    assert t0.n_objects == ka["task0"]["n_objects"]
+    for oi in (0, 1):
+        b = bps[t0.first_object + oi]
+        for k, v in ka["task0"]["object%d" % oi].items():
+            got = getattr(b, k)
+            assert (got == v) if isinstance(v, int) else (_f32(got) == _f32(v)), (oi, k, got, v)
+    o2 = bps[t0.first_object + 2]
+    e2 = ka["task0"]["object2"]
+    assert o2.obj_type == e2["obj_type"] and o2.n_components == e2["n_components"]
+    comps = [bps[o2.first_component + k] for k in range(o2.n_components)]
+    assert [c.obj_type for c in comps] == e2["component_types"]
+    assert [c.is_additive_component for c in comps] == e2["component_additive"]
+    assert _f32(comps[1].init_trans_x) == _f32(e2["component1_init_trans_x"])
+    assert _f32(comps[1].init_trans_y) == _f32(e2["component1_init_trans_y"])
+    t1 = tasks[1]
+    assert t1.n_objects == ka["task1"]["n_objects"]
+    assert _f32(bps[t1.background].rot) == _f32(ka["task1"]["bg"]["rot"])
+    assert _f32(bps[t1.background].scale) == _f32(ka["task1"]["bg"]["scale"])
+    rs = ka["raw_streams"]
+    assert [int(v) for v in oracle.rng_draws(0, 0, 0, 2147483647, n=4)] == rs["seed0_uniform_int_0_intmax"]
+    assert [_f32(v) for v in oracle.rng_draws(2, 5, n=4)] == [_f32(v) for v in rs["seed5_normal"]]
+    assert [int(v) for v in oracle.rng_draws(0, 30, 3, 20, n=4)] == rs["seed30_uniform_int_3_20"]
+    assert [int(v) for v in oracle.rng_draws(1, 11, 16, 24, n=4)] == rs["seed11_int_uniform_16_24"]
+
+
+def test_bad_mode(oracle):
+    with pytest.raises(ValueError):
+        oracle.Sampler(0)
+    with pytest.raises(ValueError):
+        oracle.Sampler(14)
+
+
+def test_rasteriser_matches_agg(oracle, agg):
+    W, H = agg["canvas"]
+    off = 0
+    for i, n in enumerate(agg["poly_len"]):
+        xy = agg["poly_xy"][off:off + n]
+        off += n
+        cov = oracle.rasterize(xy, W, H)
+        assert np.array_equal(cov, agg["poly_cov"][i]), "polygon %d" % i
+
+
+def test_curve3_matches_agg(oracle, agg):
+    off = 0
+    for i, n in enumerate(agg["curve_len"]):
+        ref = agg["curve_pts"][off:off + n]
+        off += n
+        p = agg["curve_ctrl"][i]
+        mine = oracle.curve3(p[0], p[1], p[2])
+        assert mine.shape == ref.shape and np.array_equal(mine, ref), "curve %d" % i
+
+
+def flatten_curve_polygon(oracle, xy, types):
+    pts = [xy[0]]
+    k = 1
+    n = len(xy)
+    while k < n:
+        if types[k] == 1:
+            pts.append(xy[k])
+            k += 1
+        else:
+            c = oracle.curve3(pts[-1], xy[k], xy[k + 1] if k + 1 < n else xy[0])
+            pts.extend(c[1:])
+            k += 2
+    return np.array(pts)
+
+
+def test_curve_polygons_match_agg(oracle, agg):
+    W, H = agg["canvas"]
+    off = 0
+    for i, n in enumerate(agg["cpoly_len"]):
+        xy = agg["cpoly_xy"][off:off + n]
+        types = agg["cpoly_types"][off:off + n]
+        off += n
+        cov = oracle.rasterize(flatten_curve_polygon(oracle, xy, types), W, H)
+        assert np.array_equal(cov, agg["cpoly_cov"][i]), "curve polygon %d" % i
+
+
+def agg_invert(m):
+    sx, shx, tx = m[0]
+    shy, sy, ty = m[1]
+    d = 1.0 / (sx * sy - shy * shx)
+    t0 = sy * d
+    sy2 = sx * d
+    shy2 = -shy * d
+    shx2 = -shx * d
+    t4 = -tx * t0 - ty * shx2
+    ty2 = -tx * shy2 - ty * sy2
+    return [t0, shy2, shx2, sy2, t4, ty2]
+
+
+def test_span_interpolator_matches_agg(oracle, agg):
+    SW, SH = agg["dda_src"]
+    for i, m in enumerate(agg["dda_mats"]):
+        inv = agg_invert(m)
+        pos = agg["dda_pos"][i]
+        oh, ow = pos.shape
+        for y in range(oh):
+            r = oracle.dda_row(inv, y, ow)
+            idx = (r[:, 1] >> 8) * SW + (r[:, 0] >> 8)
+            assert np.array_equal(idx, pos[y]), (i, y)
+
+
+def test_identity_texture_warp_is_a_copy(oracle):
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (3, 24, 40)).astype(np.uint8)
+    out = oracle.transformed_texture(img, [1, 0, 0, 1, 0, 0])
+    assert np.array_equal(out, img)
+    # integer translation: shifted copy with reflect wrap
+    out = oracle.transformed_texture(img, [1, 0, 0, 1, 3, 0])
+    assert np.array_equal(out[:, :, 3:], img[:, :, :-3])
+    assert np.array_equal(out[:, :, 2], img[:, :, 0]) and np.array_equal(out[:, :, 0], img[:, :, 2])
+
+
+def test_blend_is_integer_floor(oracle):
+    # CImg draw_image in fp32 == floor((m*s + (255-m)*d)/255) for all bytes
+    L = oracle.lib()
+    for s in (0, 1, 77, 200, 255):
+        for d in range(0, 256, 5):
+            for m in range(256):
+                assert L.ofdg_oracle_draw_image_value(d, s, m) == (m * s + (255 - m) * d) // 255
+
+
+def test_aa_byte_table(oracle):
+    _, _, aa = oracle.tables()
+    assert aa[0] == 0 and aa[255] == 255
+    assert all(aa[c] == c - 1 for c in range(1, 255))

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training samples/s (image0 + image1 + flow) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): FlyingChairs mode 5, 512x384, batch 32 per GPU,
+16 objects, affine-only motion, AA on, synthetic 1000 x 1024x768 texture pool.
+A "step" is one pass of the hot path (geom -> raster -> compose kernels) over one batch
+of 32 blueprinted samples.  Inputs (realised blueprints, texture pool) are resident in
+HBM when the timed region starts; NSLOT distinct batches are rotated so that no step
+re-renders the batch it rendered last (their backgrounds together exceed the 256 MiB
+Infinity Cache).  Samples shard across ranks with no data-path collective ("weak"
+scaling): rank r renders block r of every B*world consecutive samples of the stream.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, MODE, BATCH, NOBJ = 512, 384, 5, 32, 16
+POOL_N, POOL_W, POOL_H, POOL_SEED = 1000, 1024, 768, 2024
+NSLOT = 12
+ALG_BYTES_PER_SAMPLE = 38 * W * H       # 32 B/px written (8 fp32 planes) + 6 B/px background read
+HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(ofdg, gen, tasks, bps, n_bps, budget_s=15.0):
+    """The oracle (CPU restatement of the reference path, per-object full-frame work like
+    the reference) timed on this host's cores: first_level_threads = all cores,
+    second_level_threads = 1 (reference threading, DataGenerator.cpp:1023-1027)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as oracle
+    cores = os.cpu_count() or 1
+    sub = np.stack([gen.pool_download(i) for i in range(4)])  # tex_id % 4: same work, small host pool
+    prm = oracle.default_params(W, H, MODE, 1, 1, NOBJ)
+    n = min(cores, BATCH)
+    t0 = time.perf_counter()
+    oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
+    dt = time.perf_counter() - t0
+    done = n
+    # scale the sample to the budget (whole multiples of the first chunk)
+    reps = int(max(0, min((budget_s - dt) / max(dt, 1e-6), 64)))
+    for _ in range(reps):
+        oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
+        done += n
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d samples of this workload (mode %d, %dx%d, %d objects; 4-texture host pool subset), "
+                      "oracle/ restatement with the reference's per-object full-frame work, %d threads" %
+                      (done, MODE, W, H, NOBJ, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+
+    header = torch.tensor([MODE, W, H, NOBJ, POOL_N, POOL_W, POOL_H, POOL_SEED], dtype=torch.int64, device="cuda")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+        # the one collective of this path: rank 0's stream/pool description, over RCCL
+        if rank != 0:
+            header.zero_()
+        dist.broadcast(header, src=0)
+    mode, w, h, nobj, pool_n, pool_w, pool_h, pool_seed = [int(v) for v in header.tolist()]
+
+    prm = ofdg.default_params(width=w, height=h, mode=mode, num_objects=nobj, batch_size=BATCH,
+                              rank=rank, world_size=world, device=local_rank)
+    gen = ofdg.Generator(prm)
+    gen.pool_synthetic(pool_n, pool_w, pool_h, pool_seed)
+
+    # every rank walks the same reference stream and keeps its own block of each B*world tasks
+    sampler = ofdg.HostSampler(mode, w, h, nobj)
+    stream = torch.cuda.current_stream().cuda_stream
+    first = None
+    t_s = time.perf_counter()
+    for slot in range(NSLOT):
+        tasks, bps, n_bps = sampler.next(BATCH * world, cap=BATCH * world * 64)
+        mine = (ofdg.Task * BATCH)(*[tasks[rank * BATCH + i] for i in range(BATCH)])
+        gen.upload_slot(slot, mine, BATCH, bps, n_bps, stream)
+        if first is None:
+            first = (mine, bps, n_bps)
+    host_sampler_rate = NSLOT * BATCH * world / (time.perf_counter() - t_s)
+    img0, img1, flow = ofdg.alloc_outputs(BATCH, h, w)
+    gen.synchronize(stream)
+
+    for i in range(args.warmup):
+        gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+    gen.synchronize(stream)
+    gen.set_profiling(1)  # HIP events around the compose kernel, on the launch stream
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    gen.synchronize(stream)  # raises if a kernel flagged a capacity error
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    compose_ms = gen.kernel_ms("compose")
+    if rank == 0:
+        # second short pass with all three kernels timed (not part of `value`)
+        gen.set_profiling(2)
+        for i in range(min(args.steps, 48)):
+            gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+        gen.synchronize(stream)
+        parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        gen.set_profiling(0)
+        samples = args.steps * BATCH * world
+        value = samples / dt
+        achieved = BATCH * ALG_BYTES_PER_SAMPLE / (compose_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("compose_kernel_hbm_bytes_per_launch")
+        out = {
+            "metric": "training samples/sec (img0+img1+flow, 512x384)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
+            "config": {"workload": "FlyingChairs mode 5, 512x384, batch=32 per GPU, 16 objects, affine-only motion, "
+                                   "AA on, synthetic 1000x(1024x768) texture pool (BASELINE configs[1])",
+                       "batch_per_gpu": BATCH, "resident_batches": NSLOT, "sampler": "ref (host), outside the timed region"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "compose_kernel", "kernel_ms": compose_ms,
+                         "algorithmic_bytes_per_launch": BATCH * ALG_BYTES_PER_SAMPLE},
+            "kernel_ms": parts,
+            "hbm_gbs_whole_step": value / world * ALG_BYTES_PER_SAMPLE / 1e9,
+            "host_ref_sampler_samples_per_s": host_sampler_rate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ofdg, gen, first[0], first[1], first[2])
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

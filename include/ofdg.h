@@ -163,6 +163,15 @@ int ofdg_render(ofdg_ctx* ctx, const ofdg_task* tasks, int n_tasks,
 int ofdg_render_resident(ofdg_ctx* ctx, float* d_image0, float* d_image1,
                          float* d_flow, void* stream);
 
+/* Prefetch ring (maps data_param.prefetch, LAY:36-56, 141-172): up to 16 batches can be
+ * resident in HBM at once.  ofdg_upload_slot realises + uploads one batch into `slot`;
+ * ofdg_render_slot renders a resident slot (any number of times).  Slot 0 is the one
+ * ofdg_render / ofdg_render_resident use. */
+int ofdg_upload_slot(ofdg_ctx* ctx, int slot, const ofdg_task* tasks, int n_tasks,
+                     const ofdg_blueprint* bps, int n_bps, void* stream);
+int ofdg_render_slot(ofdg_ctx* ctx, int slot, float* d_image0, float* d_image1,
+                     float* d_flow, void* stream);
+
 /* Replaces Forward_cpu/Forward_gpu (LAY:266-291): sample batch_size tasks and
  * render them. */
 int ofdg_forward(ofdg_ctx* ctx, float* d_image0, float* d_image1, float* d_flow,

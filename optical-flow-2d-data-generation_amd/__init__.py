@@ -70,7 +70,7 @@ _lib = None
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
     "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
-    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_forward", "ofdg_synchronize",
+    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
@@ -91,6 +91,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OfdgError(EHIP, "libofdg.so is not built (run __graft_entry__.build()); "
                                   "the HIP extension is the only render path")
+        # PyTorch wheels bundle their own libamdhip64.so.7; a process must hold ONE HIP
+        # runtime, so when torch is installed let it load first and share its copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i32 = C.c_void_p, C.c_int
         L.ofdg_default_params.argtypes = [C.POINTER(Params)]
@@ -108,6 +114,8 @@ def lib():
         L.ofdg_sample.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
         L.ofdg_render.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
         L.ofdg_render_resident.argtypes = [vp, vp, vp, vp, vp]
+        L.ofdg_upload_slot.argtypes = [vp, i32, vp, i32, vp, i32, vp]
+        L.ofdg_render_slot.argtypes = [vp, i32, vp, vp, vp, vp]
         L.ofdg_forward.argtypes = [vp, vp, vp, vp, vp]
         L.ofdg_synchronize.argtypes = [vp, vp]
         L.ofdg_debug_rasterize.argtypes = [vp, vp, i32, vp]
@@ -211,6 +219,13 @@ class Generator:
     def render_resident(self, img0, img1, flow, stream=0):
         self._check(lib().ofdg_render_resident(self.h, _dptr(img0), _dptr(img1), _dptr(flow), C.c_void_p(stream)))
 
+    def upload_slot(self, slot, tasks, n_tasks, bps, n_bps, stream=0):
+        self._check(lib().ofdg_upload_slot(self.h, slot, C.cast(tasks, C.c_void_p), n_tasks, C.cast(bps, C.c_void_p), n_bps,
+                                           C.c_void_p(stream)))
+
+    def render_slot(self, slot, img0, img1, flow, stream=0):
+        self._check(lib().ofdg_render_slot(self.h, slot, _dptr(img0), _dptr(img1), _dptr(flow), C.c_void_p(stream)))
+
     def forward(self, img0, img1, flow, stream=0):
         self._check(lib().ofdg_forward(self.h, _dptr(img0), _dptr(img1), _dptr(flow), C.c_void_p(stream)))
 
@@ -248,8 +263,8 @@ class Generator:
                                             bl.ctypes.data_as(vp), s_fixed))
         return add, sub, aa, bl
 
-    def set_profiling(self, enabled=True):
-        self._check(lib().ofdg_set_profiling(self.h, 1 if enabled else 0))
+    def set_profiling(self, mode=2):
+        self._check(lib().ofdg_set_profiling(self.h, int(mode)))
 
     def kernel_ms(self, name):
         ms = C.c_float()

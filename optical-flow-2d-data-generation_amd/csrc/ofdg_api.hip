@@ -4,6 +4,7 @@
 // point that would render fails with OFDG_EHIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -45,26 +46,32 @@ struct ofdg_ctx {
   // sampler
   std::unique_ptr<RefSampler> sampler;
   long long step = 0;
-  // host staging (pinned) + device records
-  RealizedBatch batch;
+  // host staging (pinned) + device records.  A "slot" is one realised batch resident
+  // in HBM (shapes, objects, samples, outlines); slot 0 is what ofdg_render uses, the
+  // others let a caller keep several batches in flight (data_param.prefetch).
+  struct Slot {
+    RealizedBatch batch;
+    DevBuf<DevShape> d_shapes;
+    DevBuf<DevShapeFrame> d_frames;
+    DevBuf<int2> d_verts;
+    DevBuf<DevObject> d_objects;
+    DevBuf<DevSample> d_samples;
+    int res_samples = 0, res_shapes = 0;
+  };
+  static constexpr int kSlots = 16;
+  Slot slots[kSlots];
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
   hipEvent_t stage_free = nullptr;
   bool stage_pending = false;
-  DevBuf<DevShape> d_shapes;
-  DevBuf<DevShapeFrame> d_frames;
-  DevBuf<int2> d_verts;
-  DevBuf<uint8_t> d_cov;
-  DevBuf<DevObject> d_objects;
-  DevBuf<DevSample> d_samples;
+  DevBuf<uint8_t> d_cov;  // coverage workspace, shared by all slots (stream ordered)
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
-  // resident batch
-  int res_samples = 0, res_shapes = 0;
-  // profiling
-  bool profiling = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  // profiling: ring of event sets, 4 events per launch (before geom / raster / compose, after compose)
+  int profiling = 0;  // 0 off, 1 compose kernel only, 2 all three kernels
+  std::vector<hipEvent_t> ev;
+  int ev_sets = 0;
+  long long ev_count = 0;
   std::vector<ofdg_task> fw_tasks;
   std::vector<ofdg_blueprint> fw_bps;
 };
@@ -133,8 +140,6 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  for (int i = 0; i < 4; ++i)
-    if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { g_create_error = hipGetErrorString(e); return OFDG_EHIP; }
   // the raster kernel's cell arrays may exceed the default 64 KiB of dynamic LDS
   const int lds = 2 * kBandRows * (params->width + 1) * (int)sizeof(int);
   e = hipFuncSetAttribute((const void*)raster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -151,12 +156,14 @@ void ofdg_destroy(ofdg_ctx* c) {
   (void)hipDeviceSynchronize();
   if (c->pool) (void)hipFree(c->pool);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
-  c->d_shapes.release(); c->d_frames.release(); c->d_verts.release(); c->d_cov.release();
-  c->d_objects.release(); c->d_samples.release();
+  for (auto& sl : c->slots) {
+    sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
+  }
+  c->d_cov.release();
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
-  for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -251,60 +258,62 @@ int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps,
 }
 
 // ---- render -------------------------------------------------------------------------------
-static int launch_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
+static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
   const int W = c->prm.width, H = c->prm.height;
-  const int n_sf = c->res_shapes * 2;
-  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[0], st));
+  const int n_sf = sl.res_shapes * 2;
+  hipEvent_t* ev = nullptr;
+  if (c->profiling && c->ev_sets > 0) ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
+  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], st));
   if (n_sf > 0) {
-    hipLaunchKernelGGL(geom_kernel, dim3(n_sf), dim3(128), 0, st, c->d_shapes.p, c->res_shapes, c->d_cs_tab, W, H,
-                       c->d_frames.p, c->d_verts.p, c->d_err);
+    hipLaunchKernelGGL(geom_kernel, dim3(n_sf), dim3(128), 0, st, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
+                       sl.d_frames.p, sl.d_verts.p, c->d_err);
     HIP_OK(c, hipGetLastError());
   }
-  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[1], st));
+  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], st));
   if (n_sf > 0) {
     const int bands = (H + kBandRows - 1) / kBandRows;
     const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
-    hipLaunchKernelGGL(raster_kernel, dim3(n_sf, bands), dim3(256), lds, st, c->d_frames.p, n_sf, c->d_verts.p, W, H,
+    hipLaunchKernelGGL(raster_kernel, dim3(n_sf, bands), dim3(256), lds, st, sl.d_frames.p, n_sf, sl.d_verts.p, W, H,
                        c->d_cov.p);
     HIP_OK(c, hipGetLastError());
   }
-  if (c->profiling) HIP_OK(c, hipEventRecord(c->ev[2], st));
+  if (ev) HIP_OK(c, hipEventRecord(ev[2], st));
   RenderDims dm;
   dm.W = W; dm.H = H; dm.pool_w = c->pool_w; dm.pool_h = c->pool_h;
   dm.use_aa = c->prm.use_antialiasing ? 1 : 0;
-  dm.n_samples = c->res_samples;
-  dm.n_shapes = c->res_shapes;
+  dm.n_samples = sl.res_samples;
+  dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
-  hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, c->d_samples.p,
-                     c->d_objects.p, c->d_frames.p, c->d_cov.p, c->pool, d_img0, d_img1, d_flow);
+  hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
+                     sl.d_objects.p, sl.d_frames.p, c->d_cov.p, c->pool, d_img0, d_img1, d_flow);
   HIP_OK(c, hipGetLastError());
-  if (c->profiling) { HIP_OK(c, hipEventRecord(c->ev[3], st)); c->ev_valid = true; }
+  if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
   return OFDG_OK;
 }
 
-int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
-                float* d_img0, float* d_img1, float* d_flow, void* stream) {
-  if (!c || !tasks || !bps || n_tasks < 1 || !d_img0 || !d_img1 || !d_flow) {
-    if (c) c->err = "ofdg_render: invalid argument";
-    return OFDG_EINVAL;
-  }
+// realise on the host, stage, and copy the records of one batch into slot `sl`
+static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
+                       int n_bps, hipStream_t st) {
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
-  hipStream_t st = (hipStream_t)stream;
   RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h};
   // the previous call's host->device copies must have left the staging buffer
   if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
-  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &c->batch, &c->err);
+  sl.res_samples = 0;
+  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &sl.batch, &c->err);
   if (rc != OFDG_OK) return rc;
-  const RealizedBatch& B = c->batch;
+  const RealizedBatch& B = sl.batch;
   const size_t n_shapes = B.shapes.size(), n_obj = B.objects.size();
   const int W = c->prm.width, H = c->prm.height;
-  HIP_OK(c, c->d_shapes.reserve(n_shapes));
-  HIP_OK(c, c->d_frames.reserve(n_shapes * 2));
-  HIP_OK(c, c->d_verts.reserve(n_shapes * 2 * kMaxVerts));
-  HIP_OK(c, c->d_cov.reserve(n_shapes * 2 * (size_t)W * H + 16));
-  HIP_OK(c, c->d_objects.reserve(n_obj));
-  HIP_OK(c, c->d_samples.reserve(n_tasks));
+  HIP_OK(c, sl.d_shapes.reserve(n_shapes));
+  HIP_OK(c, sl.d_frames.reserve(n_shapes * 2));
+  HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
+  if (n_shapes * 2 * (size_t)W * H + 16 > c->d_cov.cap) {
+    HIP_OK(c, hipDeviceSynchronize());  // other slots' launches may still use the workspace
+    HIP_OK(c, c->d_cov.reserve(n_shapes * 2 * (size_t)W * H + 16));
+  }
+  HIP_OK(c, sl.d_objects.reserve(n_obj));
+  HIP_OK(c, sl.d_samples.reserve(n_tasks));
   const size_t b_shapes = n_shapes * sizeof(DevShape), b_obj = n_obj * sizeof(DevObject),
                b_smp = (size_t)n_tasks * sizeof(DevSample);
   const size_t need = b_shapes + b_obj + b_smp + 64;
@@ -318,20 +327,44 @@ int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blu
   if (b_shapes) std::memcpy(hs, B.shapes.data(), b_shapes);
   std::memcpy(hs + b_shapes, B.objects.data(), b_obj);
   std::memcpy(hs + b_shapes + b_obj, B.samples.data(), b_smp);
-  if (b_shapes) HIP_OK(c, hipMemcpyAsync(c->d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
-  HIP_OK(c, hipMemcpyAsync(c->d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
-  HIP_OK(c, hipMemcpyAsync(c->d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
+  if (b_shapes) HIP_OK(c, hipMemcpyAsync(sl.d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemcpyAsync(sl.d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemcpyAsync(sl.d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipEventRecord(c->stage_free, st));
   c->stage_pending = true;
-  c->res_samples = n_tasks;
-  c->res_shapes = (int)n_shapes;
-  return launch_resident(c, d_img0, d_img1, d_flow, st);
+  sl.res_samples = n_tasks;
+  sl.res_shapes = (int)n_shapes;
+  return OFDG_OK;
+}
+
+int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
+                float* d_img0, float* d_img1, float* d_flow, void* stream) {
+  if (!c || !tasks || !bps || n_tasks < 1 || !d_img0 || !d_img1 || !d_flow) {
+    if (c) c->err = "ofdg_render: invalid argument";
+    return OFDG_EINVAL;
+  }
+  int rc = upload_slot(c, c->slots[0], tasks, n_tasks, bps, n_bps, (hipStream_t)stream);
+  if (rc != OFDG_OK) return rc;
+  return launch_resident(c, c->slots[0], d_img0, d_img1, d_flow, (hipStream_t)stream);
+}
+
+int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
+                     void* stream) {
+  if (!c || !tasks || !bps || n_tasks < 1 || slot < 0 || slot >= ofdg_ctx::kSlots) {
+    if (c) c->err = "ofdg_upload_slot: invalid argument";
+    return OFDG_EINVAL;
+  }
+  return upload_slot(c, c->slots[slot], tasks, n_tasks, bps, n_bps, (hipStream_t)stream);
+}
+
+int ofdg_render_slot(ofdg_ctx* c, int slot, float* d_img0, float* d_img1, float* d_flow, void* stream) {
+  if (!c || !d_img0 || !d_img1 || !d_flow || slot < 0 || slot >= ofdg_ctx::kSlots) return OFDG_EINVAL;
+  if (c->slots[slot].res_samples <= 0) { c->err = "ofdg_render_slot: no batch is resident in this slot"; return OFDG_EINVAL; }
+  return launch_resident(c, c->slots[slot], d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
 
 int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
-  if (!c || !d_img0 || !d_img1 || !d_flow) return OFDG_EINVAL;
-  if (c->res_samples <= 0) { c->err = "ofdg_render_resident: no batch is resident"; return OFDG_EINVAL; }
-  return launch_resident(c, d_img0, d_img1, d_flow, (hipStream_t)stream);
+  return ofdg_render_slot(c, 0, d_img0, d_img1, d_flow, stream);
 }
 
 int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
@@ -387,40 +420,41 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   else { x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, W - 1); y1 = std::min(y1, H - 1); }
   f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
   HIP_OK(c, hipDeviceSynchronize());
-  HIP_OK(c, c->d_frames.reserve(2));
-  HIP_OK(c, c->d_verts.reserve(2 * kMaxVerts));
+  ofdg_ctx::Slot& sl = c->slots[0];
+  HIP_OK(c, sl.d_frames.reserve(2));
+  HIP_OK(c, sl.d_verts.reserve(2 * kMaxVerts));
   HIP_OK(c, c->d_cov.reserve((size_t)2 * W * H + 16));
-  HIP_OK(c, hipMemcpy(c->d_frames.p, &f, sizeof(f), hipMemcpyHostToDevice));
-  HIP_OK(c, hipMemcpy(c->d_verts.p, v.data(), sizeof(int2) * kMaxVerts, hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(sl.d_frames.p, &f, sizeof(f), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(sl.d_verts.p, v.data(), sizeof(int2) * kMaxVerts, hipMemcpyHostToDevice));
   HIP_OK(c, hipMemset(c->d_cov.p, 0xAB, (size_t)W * H));  // poison: only the bbox may be read back
   const int bands = (H + kBandRows - 1) / kBandRows;
   const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
-  hipLaunchKernelGGL(raster_kernel, dim3(1, bands), dim3(256), lds, 0, c->d_frames.p, 1, c->d_verts.p, W, H, c->d_cov.p);
+  hipLaunchKernelGGL(raster_kernel, dim3(1, bands), dim3(256), lds, 0, sl.d_frames.p, 1, sl.d_verts.p, W, H, c->d_cov.p);
   HIP_OK(c, hipGetLastError());
   std::vector<uint8_t> tmp((size_t)W * H);
   HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p, tmp.size(), hipMemcpyDeviceToHost));
   std::memset(coverage_host, 0, tmp.size());
   for (int y = y0; y <= y1; ++y)
     for (int x = x0; x <= x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
-  c->res_samples = 0;  // the workspaces no longer hold a rendered batch
+  for (auto& s2 : c->slots) s2.res_samples = 0;  // the workspaces no longer hold a rendered batch
   return OFDG_OK;
 }
 
 int ofdg_debug_num_shapes(ofdg_ctx* c, int sample) {
-  if (!c || sample < 0 || sample >= (int)c->batch.samples.size() || c->res_samples <= 0) return OFDG_EINVAL;
-  return c->batch.samples[sample].n_shapes;
+  if (!c || c->slots[0].res_samples <= 0 || sample < 0 || sample >= (int)c->slots[0].batch.samples.size()) return OFDG_EINVAL;
+  return c->slots[0].batch.samples[sample].n_shapes;
 }
 
 int ofdg_debug_coverage(ofdg_ctx* c, int sample, int shape, int frame, uint8_t* coverage_host) {
-  if (!c || !coverage_host || frame < 0 || frame > 1 || c->res_samples <= 0) return OFDG_EINVAL;
-  if (sample < 0 || sample >= (int)c->batch.samples.size()) return OFDG_EINVAL;
-  const DevSample& s = c->batch.samples[sample];
+  if (!c || !coverage_host || frame < 0 || frame > 1 || c->slots[0].res_samples <= 0) return OFDG_EINVAL;
+  if (sample < 0 || sample >= (int)c->slots[0].batch.samples.size()) return OFDG_EINVAL;
+  const DevSample& s = c->slots[0].batch.samples[sample];
   if (shape < 0 || shape >= s.n_shapes) return OFDG_EINVAL;
   const int W = c->prm.width, H = c->prm.height;
   const size_t sf = (size_t)(s.first_shape + shape) * 2 + frame;
   HIP_OK(c, hipDeviceSynchronize());
   DevShapeFrame f;
-  HIP_OK(c, hipMemcpy(&f, c->d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(&f, c->slots[0].d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
   std::vector<uint8_t> tmp((size_t)W * H);
   HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
   std::memset(coverage_host, 0, tmp.size());
@@ -429,23 +463,42 @@ int ofdg_debug_coverage(ofdg_ctx* c, int sample, int shape, int frame, uint8_t* 
   return OFDG_OK;
 }
 
-int ofdg_set_profiling(ofdg_ctx* c, int enabled) {
-  if (!c) return OFDG_EINVAL;
-  c->profiling = enabled != 0;
-  c->ev_valid = false;
+int ofdg_set_profiling(ofdg_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return OFDG_EINVAL;
+  HIP_OK(c, hipDeviceSynchronize());
+  c->profiling = mode;
+  c->ev_count = 0;
+  if (mode && c->ev.empty()) {
+    c->ev_sets = 256;
+    c->ev.resize((size_t)c->ev_sets * 4);
+    for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
+  }
   return OFDG_OK;
 }
 
+// Average device time (ms) per launch of one kernel over the launches recorded since
+// ofdg_set_profiling (at most the last 256), from HIP events on the launch stream.
 int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   if (!c || !kernel || !ms) return OFDG_EINVAL;
-  if (!c->ev_valid) { c->err = "no profiled render yet (ofdg_set_profiling)"; return OFDG_EINVAL; }
   int i = -1;
   if (!std::strcmp(kernel, "geom")) i = 0;
   else if (!std::strcmp(kernel, "raster")) i = 1;
   else if (!std::strcmp(kernel, "compose")) i = 2;
   if (i < 0) { c->err = "unknown kernel name"; return OFDG_EINVAL; }
-  HIP_OK(c, hipEventSynchronize(c->ev[3]));
-  HIP_OK(c, hipEventElapsedTime(ms, c->ev[i], c->ev[i + 1]));
+  if (!c->profiling || c->ev_count == 0 || (i < 2 && c->profiling != 2)) {
+    c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)";
+    return OFDG_EINVAL;
+  }
+  const int n = (int)std::min<long long>(c->ev_count, c->ev_sets);
+  double acc = 0;
+  for (int k = 0; k < n; ++k) {
+    hipEvent_t* ev = &c->ev[(size_t)k * 4];
+    HIP_OK(c, hipEventSynchronize(ev[3]));
+    float t = 0;
+    HIP_OK(c, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+    acc += t;
+  }
+  *ms = (float)(acc / n);
   return OFDG_OK;
 }
 

@@ -309,9 +309,12 @@ class HostSampler:
         return tasks, bps, n.value
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ofdg_host_sampler_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().ofdg_host_sampler_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def host_realize(params, pool_n, pool_w, pool_h, tasks, n_tasks, bps, n_bps, cap=4096):

@@ -41,184 +41,270 @@ __device__ __forceinline__ long long floordiv64(long long a, long long b) {
 }
 
 // --------------------------------------------------------------------------
-// geom_kernel: one workgroup per (shape, frame).
+// wave-level helpers (wave64)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+  return v;
+}
+// inclusive prefix sum over the 64 lanes: DPP row shifts + row broadcasts (gfx9 DPP)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// --------------------------------------------------------------------------
+// geom_kernel: one WAVE per (shape, frame), four per workgroup.
 // Reference: RealizeObjectBlueprint geometry (DG:1073-1117), conv_transform +
 // conv_curve feeding rasterizer_scanline_aa::add_path (DG:465-479, 520-534),
 // agg::ellipse (100 steps), agg::curve3_div, ras_conv_int::upscale = iround(v*256).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
+constexpr int kGeomWaves = 4;
+constexpr int kCurveSlots = 10;  // a polygon of <= 20 segments holds <= 9 curve3 segments
+
+// curve3_div::recursive_bezier as an explicit depth-first walk (left subtree first).
+// Writes the subdivision points followed by the end point to `out` (24.8 fixed point)
+// and returns how many.  `stack` holds the pending right halves: the start of a popped
+// half is the end of the half just finished, so 4 doubles + the level suffice.
+__device__ __forceinline__ int flatten_curve3(double x1, double y1, double x2, double y2, double x3, double y3,
+                                              double (*stack)[5], int2* out, int cap, bool* overflow) {
+  const double ex = x3, ey = y3;
+  const double tol_sq = 0.25;  // (0.5 / approximation_scale)^2
+  int cnt = 0, sp = 0, level = 0;
+  for (;;) {
+    bool subdivide = false;
+    if (level <= 32) {  // curve_recursion_limit
+      const double x12 = (x1 + x2) / 2, y12 = (y1 + y2) / 2;
+      const double x23 = (x2 + x3) / 2, y23 = (y2 + y3) / 2;
+      const double x123 = (x12 + x23) / 2, y123 = (y12 + y23) / 2;
+      const double dx = x3 - x1, dy = y3 - y1;
+      double d = fabs(((x2 - x3) * dy - (y2 - y3) * dx));
+      bool emit = false;
+      double px = 0, py = 0;
+      if (d > 1e-30) {  // curve_collinearity_epsilon
+        if (d * d <= tol_sq * (dx * dx + dy * dy)) { emit = true; px = x123; py = y123; }
+        else subdivide = true;
+      } else {
+        const double da = dx * dx + dy * dy;
+        bool stop = false;
+        if (da == 0) {
+          d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+        } else {
+          d = ((x2 - x1) * dx + (y2 - y1) * dy) / da;
+          if (d > 0 && d < 1) stop = true;
+          else if (d <= 0) d = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2);
+          else d = (x3 - x2) * (x3 - x2) + (y3 - y2) * (y3 - y2);
+        }
+        if (!stop) {
+          if (d < tol_sq) { emit = true; px = x2; py = y2; }
+          else subdivide = true;
+        }
+      }
+      if (emit) {
+        if (cnt < cap - 1) out[cnt++] = make_int2(iround_d(px * 256.0), iround_d(py * 256.0));
+        else *overflow = true;
+      }
+      if (subdivide) {
+        if (sp < kCurveMaxDepth) {
+          double* st = stack[sp++];
+          st[0] = x23; st[1] = y23; st[2] = x3; st[3] = y3; st[4] = (double)(level + 1);
+          x3 = x123; y3 = y123; x2 = x12; y2 = y12;  // descend into the left half
+          ++level;
+          continue;
+        }
+        *overflow = true;
+      }
+    }
+    if (sp == 0) break;
+    const double* st = stack[--sp];
+    x1 = x3; y1 = y3;  // the right half starts where the left half ended
+    x2 = st[0]; y2 = st[1]; x3 = st[2]; y3 = st[3]; level = (int)st[4];
+  }
+  out[cnt++] = make_int2(iround_d(ex * 256.0), iround_d(ey * 256.0));
+  return cnt;
+}
+
+// Object boxes are stored as {x0, y0, -x1, -y1} so that one atomicMin grows them and
+// one byte pattern (0x7F) empties them.
+constexpr int kEmptyBox = 0x7F7F7F7F;
+
+__global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
                                                    const double* __restrict__ cs_tab, int W, int H,
                                                    DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
-                                                   uint32_t* __restrict__ err) {
-  __shared__ int s_cnt[kMaxSegments + 1];
-  __shared__ int s_bbox[4];
-  __shared__ int2 s_stage[kMaxSegments][kCurveMaxPts];
-  __shared__ double s_stack[kMaxSegments][kCurveMaxDepth][7];
-
-  const int sf = blockIdx.x;
-  if (sf >= n_shapes * 2) return;
-  const int tid = threadIdx.x;
+                                                   int4* __restrict__ obj_box, uint32_t* __restrict__ err,
+                                                   int* __restrict__ item_count) {
+  __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
+  __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // consumed by bin_kernel (next launch)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
+  if (sf >= n_shapes * 2) return;  // wave-uniform
   const DevShape& S = shapes[sf >> 1];
   const Mat M = S.m[sf & 1];
   int2* out = verts + (size_t)sf * kMaxVerts;
 
-  if (tid == 0) {
-    s_bbox[0] = 0x7FFFFFFF; s_bbox[1] = 0x7FFFFFFF;
-    s_bbox[2] = (int)0x80000000; s_bbox[3] = (int)0x80000000;
-  }
-  if (tid <= kMaxSegments) s_cnt[tid] = 0;
-  __syncthreads();
-
   int n_verts = 0;
+  int minx = 0x7FFFFFFF, miny = 0x7FFFFFFF, maxx = (int)0x80000000, maxy = (int)0x80000000;
   if (S.type == 1) {
     // agg::ellipse::vertex: x = cx + cos(angle)*rx with angle = step/100 * 2*pi; the
     // cos/sin table comes from the host's libm so the doubles match the CPU's.
     n_verts = 100;
-    if (tid < 100) {
-      double x = 0.0 + cs_tab[2 * tid] * (double)S.rx;
-      double y = 0.0 + cs_tab[2 * tid + 1] * (double)S.ry;
+    for (int k = lane; k < 100; k += 64) {
+      double x = 0.0 + cs_tab[2 * k] * (double)S.rx;
+      double y = 0.0 + cs_tab[2 * k + 1] * (double)S.ry;
       xform(M, x, y);
-      int2 v = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
-      out[tid] = v;
-      atomicMin(&s_bbox[0], v.x); atomicMin(&s_bbox[1], v.y);
-      atomicMax(&s_bbox[2], v.x); atomicMax(&s_bbox[3], v.y);
+      const int2 v = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
+      out[k] = v;
+      minx = min(minx, v.x); maxx = max(maxx, v.x);
+      miny = min(miny, v.y); maxy = max(maxy, v.y);
     }
   } else {
     const int n_seg = S.n_seg;
-    // pass 1: every segment flattens into its staging row
-    if (tid < n_seg) {
-      const int t = (tid == 0) ? 1 : S.seg_type[tid];  // segment 0 is the move_to vertex
-      int cnt = 0;
-      if (t == 1) {
-        double x = (double)S.seg_x[tid], y = (double)S.seg_y[tid];
-        xform(M, x, y);
-        s_stage[tid][0] = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
-        cnt = 1;
-      } else if (t == 3) {
+    // segment i: 0 = the move_to vertex, Line -> 1 vertex, Curve3 -> its flattening
+    // (all but the first point), the Dummy after a Curve3 (its end point) -> nothing
+    const int t = (lane >= n_seg) ? 0 : (lane == 0 ? 1 : S.seg_type[lane]);
+    const bool is_curve = (t == 3);
+    const unsigned long long cmask = __ballot(is_curve);
+    const int slot = __popcll(cmask & ((1ull << lane) - 1ull));
+    bool overflow = false;
+    int cnt = 0;
+    int2 v0 = make_int2(0, 0);
+    if (t == 1) {
+      double x = (double)S.seg_x[lane], y = (double)S.seg_y[lane];
+      xform(M, x, y);
+      v0 = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
+      cnt = 1;
+    } else if (is_curve) {
+      if (slot < kCurveSlots) {
         // conv_curve: curve3(ctrl = seg[i], to = seg[i+1]) from the current point seg[i-1]
-        double x1 = (double)S.seg_x[tid - 1], y1 = (double)S.seg_y[tid - 1];
-        double x2 = (double)S.seg_x[tid], y2 = (double)S.seg_y[tid];
-        const int ie = (tid + 1 < n_seg) ? tid + 1 : tid;
+        double x1 = (double)S.seg_x[lane - 1], y1 = (double)S.seg_y[lane - 1];
+        double x2 = (double)S.seg_x[lane], y2 = (double)S.seg_y[lane];
+        const int ie = (lane + 1 < n_seg) ? lane + 1 : lane;
         double x3 = (double)S.seg_x[ie], y3 = (double)S.seg_y[ie];
         xform(M, x1, y1); xform(M, x2, y2); xform(M, x3, y3);
-        const double ex = x3, ey = y3;
-        // curve3_div::recursive_bezier as an explicit depth-first walk
-        const double tol_sq = 0.25;  // (0.5 / approximation_scale)^2
-        int sp = 0;
-        int level = 0;
-        bool have = true, bad = false;
-        while (have) {
-          bool subdivide = false;
-          if (level <= 32) {  // curve_recursion_limit
-            const double x12 = (x1 + x2) / 2, y12 = (y1 + y2) / 2;
-            const double x23 = (x2 + x3) / 2, y23 = (y2 + y3) / 2;
-            const double x123 = (x12 + x23) / 2, y123 = (y12 + y23) / 2;
-            const double dx = x3 - x1, dy = y3 - y1;
-            double d = fabs(((x2 - x3) * dy - (y2 - y3) * dx));
-            bool emit = false;
-            double px = 0, py = 0;
-            if (d > 1e-30) {  // curve_collinearity_epsilon
-              if (d * d <= tol_sq * (dx * dx + dy * dy)) { emit = true; px = x123; py = y123; }
-              else subdivide = true;
-            } else {
-              const double da = dx * dx + dy * dy;
-              bool stop = false;
-              if (da == 0) {
-                d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
-              } else {
-                d = ((x2 - x1) * dx + (y2 - y1) * dy) / da;
-                if (d > 0 && d < 1) stop = true;
-                else if (d <= 0) d = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2);
-                else d = (x3 - x2) * (x3 - x2) + (y3 - y2) * (y3 - y2);
-              }
-              if (!stop) {
-                if (d < tol_sq) { emit = true; px = x2; py = y2; }
-                else subdivide = true;
-              }
-            }
-            if (emit) {
-              if (cnt < kCurveMaxPts - 1) s_stage[tid][cnt++] = make_int2(iround_d(px * 256.0), iround_d(py * 256.0));
-              else bad = true;
-            }
-            if (subdivide) {
-              if (sp < kCurveMaxDepth) {
-                double* st = s_stack[tid][sp++];
-                st[0] = x123; st[1] = y123; st[2] = x23; st[3] = y23; st[4] = x3; st[5] = y3; st[6] = (double)(level + 1);
-                // descend into the left half
-                x3 = x123; y3 = y123; x2 = x12; y2 = y12;
-                level = level + 1;
-                continue;
-              }
-              bad = true;
-            }
-          }
-          if (sp > 0) {
-            const double* st = s_stack[tid][--sp];
-            x1 = st[0]; y1 = st[1]; x2 = st[2]; y2 = st[3]; x3 = st[4]; y3 = st[5]; level = (int)st[6];
-          } else {
-            have = false;
-          }
-        }
-        s_stage[tid][cnt++] = make_int2(iround_d(ex * 256.0), iround_d(ey * 256.0));
-        if (bad) atomicOr(err, kErrCurveCapacity);
+        cnt = flatten_curve3(x1, y1, x2, y2, x3, y3, s_stack[wave][slot], s_stage[wave][slot], kCurveMaxPts, &overflow);
+      } else {
+        overflow = true;
       }
-      s_cnt[tid] = cnt;
     }
-    __syncthreads();
-    if (tid == 0) {  // exclusive scan over <= 20 segments
-      int acc = 0;
-      for (int i = 0; i < n_seg; ++i) { int c = s_cnt[i]; s_cnt[i] = acc; acc += c; }
-      s_cnt[kMaxSegments] = acc;
-    }
-    __syncthreads();
-    n_verts = s_cnt[kMaxSegments];
+    const int incl = wave_scan_incl(cnt);
+    n_verts = __shfl(incl, 63, 64);
+    const int off = incl - cnt;
     if (n_verts > kMaxVerts) {
-      if (tid == 0) atomicOr(err, kErrVertCapacity);
+      if (lane == 0) atomicOr(err, kErrVertCapacity);
       n_verts = 0;
-    } else if (tid < n_seg) {
-      const int off = s_cnt[tid];
-      const int end = (tid + 1 < n_seg) ? s_cnt[tid + 1] : n_verts;
-      for (int k = 0; k < end - off; ++k) {
-        int2 v = s_stage[tid][k];
+    } else if (t == 1) {
+      out[off] = v0;
+      minx = v0.x; maxx = v0.x; miny = v0.y; maxy = v0.y;
+    } else if (cnt > 0) {
+      for (int k = 0; k < cnt; ++k) {
+        const int2 v = s_stage[wave][slot][k];
         out[off + k] = v;
-        atomicMin(&s_bbox[0], v.x); atomicMin(&s_bbox[1], v.y);
-        atomicMax(&s_bbox[2], v.x); atomicMax(&s_bbox[3], v.y);
+        minx = min(minx, v.x); maxx = max(maxx, v.x);
+        miny = min(miny, v.y); maxy = max(maxy, v.y);
       }
     }
+    if (overflow) atomicOr(err, kErrCurveCapacity);
   }
-  __syncthreads();
-  if (tid == 0) {
+  minx = wave_min(minx); miny = wave_min(miny); maxx = wave_max(maxx); maxy = wave_max(maxy);
+  if (lane == 0) {
     DevShapeFrame f;
-    f.n_verts = n_verts;
     f.pad[0] = f.pad[1] = f.pad[2] = 0;
-    int x0 = s_bbox[0] >> 8, y0 = s_bbox[1] >> 8, x1 = s_bbox[2] >> 8, y1 = s_bbox[3] >> 8;
     // AGG dx_limit: an edge spanning >= 16384 px takes a different code path in
     // rasterizer_cells_aa::line; blueprints never get close, flag it if one does.
-    if (n_verts > 0 && ((long long)s_bbox[2] - (long long)s_bbox[0] >= (16384LL << 8))) {
+    if (n_verts > 0 && ((long long)maxx - (long long)minx >= (16384LL << 8))) {
       atomicOr(err, kErrDxLimit);
       n_verts = 0;
     }
+    int x0 = minx >> 8, y0 = miny >> 8, x1 = maxx >> 8, y1 = maxy >> 8;
     if (n_verts < 2 || x1 < 0 || y1 < 0 || x0 > W - 1 || y0 > H - 1) {
       x0 = 1; x1 = 0; y0 = 1; y1 = 0;  // nothing on screen
     } else {
       x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+      int* box = reinterpret_cast<int*>(&obj_box[S.object * 2 + (sf & 1)]);  // union over the object's outlines, per frame
+      atomicMin(box + 0, x0); atomicMin(box + 1, y0); atomicMin(box + 2, -x1); atomicMin(box + 3, -y1);
     }
+    f.n_verts = n_verts;
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
     frames[sf] = f;
   }
 }
 
 // --------------------------------------------------------------------------
-// raster_kernel: one workgroup per (shape-frame, band of kBandRows scanlines).
+// bin_kernel: (a) per (sample, tile): bit mask of the foreground objects whose masks can
+// touch the tile (the object's box = union of the bounding boxes of all its outlines,
+// per frame, accumulated by geom_kernel), at the granularity of 64 x 8 blocks; (b) the
+// raster work list: for every outline of an on-screen object, one item per 8-row band x
+// 128-column chunk of the blocks the object's box touches in that frame -- so compose can
+// read the coverage of a touched block unmasked.
+// --------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 16, kPx = 4;
+constexpr int kChunkW = 128;  // columns one raster item covers
+
+__global__ __launch_bounds__(256) void bin_kernel(RenderDims dm, const DevSample* __restrict__ samples,
+                                                  const DevShape* __restrict__ shapes,
+                                                  const int4* __restrict__ obj_box,
+                                                  unsigned long long* __restrict__ tile_masks,
+                                                  int4* __restrict__ items, int* __restrict__ item_count) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bands = (dm.H + kBandRows - 1) / kBandRows;
+  // (a) one thread per (sample, band, tile column, frame): object mask of that 64 x 8 block
+  const int n_mask_threads = dm.n_samples * bands * dm.tiles_x * 2;
+  if (gid < n_mask_threads) {
+    const int fr = gid & 1;
+    const int cell = gid >> 1;
+    const int tx = cell % dm.tiles_x;
+    const int band = (cell / dm.tiles_x) % bands;
+    const int s = cell / (dm.tiles_x * bands);
+    const int tx0 = tx * kTileW, by0 = band * kBandRows;
+    const DevSample smp = samples[s];
+    unsigned long long m = 0;
+    for (int oi = 1; oi < smp.n_objects; ++oi) {
+      const int4 b = obj_box[(smp.first_object + oi) * 2 + fr];  // {x0, y0, -x1, -y1}; empty: x0 > x1
+      if (b.x <= tx0 + kTileW - 1 && -b.z >= tx0 && b.y <= by0 + kBandRows - 1 && -b.w >= by0 && b.x <= -b.z)
+        m |= 1ull << (oi - 1);
+    }
+    tile_masks[gid] = m;
+    return;
+  }
+  // (b) raster items: one thread per (shape-frame, band of kBandRows rows)
+  const int j = gid - n_mask_threads;
+  if (j >= dm.n_shapes * 2 * bands) return;
+  const int sf = j / bands, band = j - sf * bands;
+  const int4 b = obj_box[shapes[sf >> 1].object * 2 + (sf & 1)];
+  const int x0 = b.x, y0 = b.y, x1 = -b.z, y1 = -b.w;
+  if (x0 > x1) return;
+  const int by0 = band * kBandRows;
+  if (by0 + kBandRows - 1 < y0 || by0 > y1) return;
+  const int xa = (x0 / kTileW) * kTileW, xb = min((x1 / kTileW) * kTileW + kTileW - 1, dm.W - 1);
+  const int nchunks = (xb - xa + kChunkW) / kChunkW;
+  int at = atomicAdd(item_count, nchunks);
+  for (int cx = xa; cx <= xb; cx += kChunkW) items[at++] = make_int4(sf, band, cx, min(cx + kChunkW - 1, xb));
+}
+
+// --------------------------------------------------------------------------
+// raster_kernel: persistent workgroups walk the item list; one item = one outline x one
+// band of kBandRows scanlines x the padded column range [X0, X1].
 //
 // AGG's rasterizer_cells_aa walks each edge scanline by scanline and cell by cell
 // with incremental lift/rem/mod stepping.  Its per-cell sums of (cover, area) are
 // order independent, and the stepping has a closed form (floor of the cumulative
 // rational), so every (edge, scanline) pair is processed by its own thread and
 // accumulated into LDS with integer atomics.  Column 0 of a row collects the cover
-// of all cells left of the shape's on-screen bounding box.
+// of all cells left of the column range.
 // Then rasterizer_scanline_aa::sweep_scanline: running cover prefix sum per row
-// (wavefront scan), alpha = min(|((C << 9) - area) >> 9|, 255) (non-zero rule,
+// (wavefront DPP scan), alpha = min(|((C << 9) - area) >> 9|, 255) (non-zero rule,
 // gamma_none).  The thresholded (gamma_threshold 0.5) mask is alpha >= 128.
 // Reference: MovingObjectBase::draw, DG:351-368.
 // --------------------------------------------------------------------------
@@ -239,7 +325,8 @@ struct CellAcc {
 };
 
 // rasterizer_cells_aa::render_hline(ey, xa, ya, xb, yb) in closed form.
-__device__ __forceinline__ void hline(const CellAcc& acc, int r, int xa, int ya, int xb, int yb) {
+template <class Acc>
+__device__ __forceinline__ void hline(const Acc& acc, int r, int xa, int ya, int xb, int yb) {
   if (ya == yb) return;
   const int exa = xa >> 8, exb = xb >> 8;
   const int fxa = xa & 255, fxb = xb & 255;
@@ -302,7 +389,8 @@ __device__ __forceinline__ void hline(const CellAcc& acc, int r, int xa, int ya,
 }
 
 // rasterizer_cells_aa::line restricted to scanline y (closed form of the stepping).
-__device__ __forceinline__ void edge_scanline(const CellAcc& acc, int r, int y, int x1, int y1, int x2, int y2) {
+template <class Acc>
+__device__ __forceinline__ void edge_scanline(const Acc& acc, int r, int y, int x1, int y1, int x2, int y2) {
   const int ey1 = y1 >> 8, ey2 = y2 >> 8;
   const int fy1 = y1 & 255, fy2 = y2 & 255;
   if (ey1 == ey2) {
@@ -331,71 +419,123 @@ __device__ __forceinline__ void edge_scanline(const CellAcc& acc, int r, int y, 
   }
 }
 
-__global__ __launch_bounds__(256) void raster_kernel(const DevShapeFrame* __restrict__ frames, int n_sf,
-                                                     const int2* __restrict__ verts, int W, int H,
-                                                     uint8_t* __restrict__ cov) {
-  extern __shared__ int s_cells[];  // cover[kBandRows][pitch], area[kBandRows][pitch]
-  __shared__ int2 s_verts[kMaxVerts];
-  const int sf = blockIdx.x;
-  if (sf >= n_sf) return;
-  const DevShapeFrame F = frames[sf];
-  if (F.x0 > F.x1) return;
-  const int by0 = blockIdx.y * kBandRows;
-  const int ylo = max(by0, F.y0), yhi = min(by0 + kBandRows - 1, F.y1);
-  if (ylo > yhi) return;
-
-  const int tid = threadIdx.x;
-  const int ncols = F.x1 - F.x0 + 1;
-  const int pitch = ncols + 1;
-  CellAcc acc;
-  acc.cover = s_cells;
-  acc.area = s_cells + kBandRows * pitch;
-  acc.pitch = pitch; acc.X0 = F.x0; acc.X1 = F.x1;
-
-  for (int i = tid; i < 2 * kBandRows * pitch; i += 256) s_cells[i] = 0;
-  const int nv = F.n_verts;
-  const int2* vsrc = verts + (size_t)sf * kMaxVerts;
-  for (int i = tid; i < nv; i += 256) s_verts[i] = vsrc[i];
-  __syncthreads();
-
-  // (edge, scanline) work items; the closing edge (last -> first) is edge nv-1
-  const int n_items = nv * kBandRows;
-  for (int it = tid; it < n_items; it += 256) {
-    const int r = it & (kBandRows - 1);
-    const int e = it / kBandRows;
-    const int y = by0 + r;
-    if (y < ylo || y > yhi) continue;
-    const int2 a = s_verts[e];
-    const int2 b = s_verts[(e + 1 == nv) ? 0 : e + 1];
-    edge_scanline(acc, r, y, a.x, a.y, b.x, b.y);
-  }
-  __syncthreads();
-
-  // sweep: one wave per row, 64 columns per step
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int r = wave; r < kBandRows; r += 4) {
-    const int y = by0 + r;
-    if (y < ylo || y > yhi) continue;  // wave-uniform
-    int carry = acc.cover[r * pitch];
-    uint8_t* dst = cov + ((size_t)sf * H + y) * W + F.x0;
-    for (int c0 = 0; c0 < ncols; c0 += 64) {
-      const int c = c0 + lane;
-      int cv = 0, ar = 0;
-      if (c < ncols) { cv = acc.cover[r * pitch + c + 1]; ar = acc.area[r * pitch + c + 1]; }
-      // inclusive wave prefix sum of cover
-      int s = cv;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(s, d, 64);
-        if (lane >= d) s += t;
-      }
-      const int C = carry + s;
-      int a = ((C << 9) - ar) >> 9;  // calculate_alpha: poly_subpixel_shift*2 + 1 - aa_shift = 9
-      a = a < 0 ? -a : a;
-      a = a > 255 ? 255 : a;
-      if (c < ncols) dst[c] = (uint8_t)a;
-      carry += __shfl(s, 63, 64);
+struct ChunkAcc {
+  int* cover;  // [kBandRows][kChunkW]
+  int* area;
+  int* carry;  // [kBandRows]: cover of all cells left of the chunk
+  int X0, X1;
+  __device__ __forceinline__ void add(int r, int cell, int dcover, int darea) const {
+    if (cell > X1 || dcover == 0) return;  // (darea is a multiple of dcover)
+    if (cell < X0) {
+      atomicAdd(&carry[r], dcover);
+    } else {
+      const int i = r * kChunkW + (cell - X0);
+      atomicAdd(&cover[i], dcover);
+      atomicAdd(&area[i], darea);
     }
+  }
+};
+
+constexpr int kRasterWaves = 4;
+struct ChunkCells {
+  int cover[kBandRows][kChunkW];
+  int area[kBandRows][kChunkW];
+  int carry[kBandRows];
+};
+
+// One WAVE per item (no workgroup barriers): clear its cells, accumulate every
+// (edge, scanline) pair of the outline that can reach the chunk, sweep, store.
+__global__ __launch_bounds__(256) void raster_kernel(const DevShapeFrame* __restrict__ frames,
+                                                     const int4* __restrict__ items,
+                                                     const int* __restrict__ item_count,
+                                                     const int2* __restrict__ verts, int W, int H,
+                                                     uint8_t* __restrict__ cov, int4* __restrict__ obj_box,
+                                                     int n_objects) {
+  __shared__ __attribute__((aligned(16))) ChunkCells s_cells[kRasterWaves];
+  __shared__ int s_queue[kRasterWaves][64 * kBandRows];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // bin_kernel (previous launch) has consumed the object boxes: empty them for the next batch
+  {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n_objects * 2) obj_box[gid] = make_int4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
+  }
+  ChunkCells& tc = s_cells[wave];
+  const int n_items = *item_count;
+  const int n_waves = gridDim.x * kRasterWaves;
+  for (int it = blockIdx.x * kRasterWaves + wave; it < n_items; it += n_waves) {
+    const int4 item = items[it];
+    const int sf = __builtin_amdgcn_readfirstlane(item.x);
+    const int by0 = __builtin_amdgcn_readfirstlane(item.y) * kBandRows;
+    const int X0 = __builtin_amdgcn_readfirstlane(item.z), X1 = __builtin_amdgcn_readfirstlane(item.w);
+    const DevShapeFrame F = frames[sf];
+    const int rows = min(kBandRows, H - by0);
+    const bool has_edges = (F.x0 <= F.x1) && (by0 <= F.y1) && (by0 + kBandRows - 1 >= F.y0) && (F.x0 <= X1) && (F.x1 >= X0);
+    uint8_t* dst = cov + ((size_t)sf * H + by0) * W + X0;
+    const int c2 = 2 * lane;  // this lane's two columns of the chunk
+    const bool in_range = (X0 + c2) <= X1;  // X0 is even and X1 odd (tile-aligned, W % 4 == 0)
+    if (!has_edges) {
+      if (in_range)
+        for (int r = 0; r < rows; ++r) *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = 0;
+      continue;
+    }
+    {  // clear
+      int4* z = reinterpret_cast<int4*>(&tc);
+      const int n16 = (2 * kBandRows * kChunkW) / 4;
+      for (int i = lane; i < n16; i += 64) z[i] = make_int4(0, 0, 0, 0);
+      if (lane < kBandRows) tc.carry[lane] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ChunkAcc acc;
+    acc.cover = &tc.cover[0][0]; acc.area = &tc.area[0][0]; acc.carry = &tc.carry[0];
+    acc.X0 = X0; acc.X1 = X1;
+    const int nv = F.n_verts;
+    const int2* v = verts + (size_t)sf * kMaxVerts;
+    // Lane = edge: find the scanlines of the band each edge crosses, compact the
+    // (edge, scanline) pairs that can reach the chunk into a dense queue, then let
+    // all 64 lanes work on real pairs.  The closing edge (last -> first) is edge nv-1.
+    int* queue = s_queue[wave];
+    for (int e0 = 0; e0 < nv; e0 += 64) {
+      const int e = e0 + lane;
+      int n_rows = 0, rlo = 0;
+      if (e < nv) {
+        const int2 a = v[e];
+        const int2 b = v[(e + 1 == nv) ? 0 : e + 1];
+        const int eya = a.y >> 8, eyb = b.y >> 8;
+        rlo = max(min(eya, eyb), by0);
+        const int rhi = min(max(eya, eyb), by0 + rows - 1);
+        if (rhi >= rlo && (min(a.x, b.x) >> 8) <= X1 && a.y != b.y) n_rows = rhi - rlo + 1;
+      }
+      const int incl = wave_scan_incl(n_rows);
+      const int total = __shfl(incl, 63, 64);
+      int at = incl - n_rows;
+      for (int k = 0; k < n_rows; ++k) queue[at++] = (e << 4) | (rlo + k - by0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      for (int q0 = 0; q0 < total; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < total) {
+          const int code = queue[q];
+          const int ee = code >> 4, r = code & 15;
+          const int2 a = v[ee];
+          const int2 b = v[(ee + 1 == nv) ? 0 : ee + 1];
+          edge_scanline(acc, r, by0 + r, a.x, a.y, b.x, b.y);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // sweep: lane l owns columns 2l, 2l+1 of every row
+    for (int r = 0; r < rows; ++r) {
+      const int2 cv = *reinterpret_cast<const int2*>(&tc.cover[r][c2]);
+      const int2 ar = *reinterpret_cast<const int2*>(&tc.area[r][c2]);
+      const int s2 = cv.x + cv.y;
+      const int base = tc.carry[r] + wave_scan_incl(s2) - s2;
+      int a0 = ((base + cv.x) << 9) - ar.x, a1 = ((base + s2) << 9) - ar.y;  // calculate_alpha (shift 9)
+      a0 >>= 9; a1 >>= 9;
+      a0 = a0 < 0 ? -a0 : a0; a1 = a1 < 0 ? -a1 : a1;
+      a0 = a0 > 255 ? 255 : a0; a1 = a1 > 255 ? 255 : a1;
+      if (in_range) *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = (uint16_t)(a0 | (a1 << 8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the next item's clear
   }
 }
 
@@ -482,10 +622,11 @@ __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__
   const int ya = wrap_reflect(y_lr, g.th, g.th2, g.my2, ry);
   const int xb = wrap_next(rx, g.tw, g.tw2);
   const int yb = wrap_next(ry, g.th, g.th2);
-  const uint32_t p00 = tex[(size_t)ya * g.pitch + xa];
-  const uint32_t p10 = tex[(size_t)ya * g.pitch + xb];
-  const uint32_t p01 = tex[(size_t)yb * g.pitch + xa];
-  const uint32_t p11 = tex[(size_t)yb * g.pitch + xb];
+  const uint32_t ra = (uint32_t)(ya * g.pitch), rb = (uint32_t)(yb * g.pitch);
+  const uint32_t p00 = tex[ra + (uint32_t)xa];
+  const uint32_t p10 = tex[ra + (uint32_t)xb];
+  const uint32_t p01 = tex[rb + (uint32_t)xa];
+  const uint32_t p11 = tex[rb + (uint32_t)xb];
   const uint32_t w00 = (256 - x_hr) * (256 - y_hr), w10 = x_hr * (256 - y_hr);
   const uint32_t w01 = (256 - x_hr) * y_hr, w11 = x_hr * y_hr;
   uint32_t out = 0;
@@ -499,16 +640,15 @@ __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__
   return out;
 }
 
-constexpr int kTileW = 64, kTileH = 16, kPx = 4;
-
-// One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a
-// 64 x 16 tile.  Objects are visited in painter's order (ascending ID); objects
-// whose masks cannot touch the tile are skipped with scalar tests.
+// One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a 64 x 16
+// tile.  Objects are visited in painter's order (ascending ID) through the tile's object
+// bit mask; their coverage comes from the slots raster_kernel filled (valid over every
+// touched tile, zero outside the outlines).
 // Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799,
 // computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
 __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSample* __restrict__ samples,
                                                       const DevObject* __restrict__ objects,
-                                                      const DevShapeFrame* __restrict__ frames,
+                                                      const unsigned long long* __restrict__ tile_masks,
                                                       const uint8_t* __restrict__ cov,
                                                       const uint32_t* __restrict__ pool,
                                                       float* __restrict__ img0, float* __restrict__ img1,
@@ -534,6 +674,16 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
 
   const DevSample smp = samples[s];
   const DevObject* objs = objects + smp.first_object;
+  // every wave covers 4 rows: waves 0,1 the upper 64 x 8 block of the tile, waves 2,3 the lower
+  const int bands = (H + kBandRows - 1) / kBandRows;
+  const int band = __builtin_amdgcn_readfirstlane(ty0 / kBandRows + (int)(threadIdx.x >> 7));
+  unsigned long long mask0 = 0, mask1 = 0;
+  if (band < bands) {
+    const size_t mi = (((size_t)s * bands + band) * dm.tiles_x + (t % dm.tiles_x)) * 2;
+    mask0 = tile_masks[mi];
+    mask1 = tile_masks[mi + 1];
+  }
+  unsigned long long omask = mask0 | mask1;
 
   int f0[3][kPx], f1[3][kPx];
   float fu[kPx], fv[kPx];
@@ -551,9 +701,11 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
     const int yy = y + H / 2, xx = x0 + W / 2;
     if (inside) {
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
-      const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (size_t)yy * g.pitch + xx);
+      const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
       const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
       const RowDDA R = make_row(B.tex_inv, yy, g.tw);
+      // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
+      const double by = (double)(y + H / 2) + (double)(-H);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         const uint32_t t1 = sample_bilinear(tex, g, R, xx + p);
@@ -562,12 +714,11 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
           f0[c][p] = (tt[p] >> (8 * c)) & 255;
           f1[c][p] = (t1 >> (8 * c)) & 255;
         }
-        // MovingObjectBackground::getPointFlow (DG:692-718)
-        double ix = (double)(x0 + p + W / 2), iy = (double)(y + H / 2);
-        const float save_x = (float)ix, save_y = (float)iy;
-        ix = ix * 1.0 + iy * 0.0 + (double)(-W); iy = iy + (double)(-H);  // intrinsic_inv = T(-W,-H)
+        double ix = (double)(x0 + p + W / 2), iy = by;
+        const float save_x = (float)(x0 + p + W / 2), save_y = (float)(y + H / 2);
+        ix = ix + (double)(-W);
         xform(B.motion, ix, iy);
-        ix = ix + (double)W; iy = iy + (double)H;                        // intrinsic = T(W,H)
+        ix = ix + (double)W; iy = iy + (double)H;
         fu[p] = (float)(ix - (double)save_x);
         fv[p] = (float)(iy - (double)save_y);
       }
@@ -588,36 +739,27 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
   g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
   g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
   g.pitch = dm.pool_w;
+  const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
+  const size_t slot_bytes = (size_t)W * H;
 
-  for (int oi = 1; oi < smp.n_objects; ++oi) {
+  while (omask) {
+    const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
+    omask &= omask - 1;
     const DevObject& O = objs[oi];
-    // scalar cull: does any component mask touch this tile (either frame)?
-    bool touch = false;
-    for (int k = 0; k < O.n_shapes; ++k) {
-#pragma unroll
-      for (int fr = 0; fr < 2; ++fr) {
-        const DevShapeFrame& F = frames[(O.first_shape + k) * 2 + fr];
-        touch |= (F.x0 <= tx0 + kTileW - 1) && (F.x1 >= tx0) && (F.y0 <= ty0 + kTileH - 1) && (F.y1 >= ty0);
-      }
-    }
-    if (!touch) continue;
+    const bool has0 = (mask0 >> (oi - 1)) & 1ull, has1 = (mask1 >> (oi - 1)) & 1ull;  // wave-uniform
 
     int m0[kPx], m1[kPx];   // blending masks for the two frames
     int na0[kPx];           // thresholded frame-0 mask (index image)
     if (O.kind == 1) {
-      const int sf0 = O.first_shape * 2;
-      const DevShapeFrame& F0 = frames[sf0];
-      const DevShapeFrame& F1 = frames[sf0 + 1];
-      const bool r0 = inside && y >= F0.y0 && y <= F0.y1;
-      const bool r1 = inside && y >= F1.y0 && y <= F1.y1;
+      const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
       uint32_t c0w = 0, c1w = 0;
-      if (r0) c0w = *reinterpret_cast<const uint32_t*>(cov + ((size_t)sf0 * H + y) * W + x0);
-      if (r1) c1w = *reinterpret_cast<const uint32_t*>(cov + ((size_t)(sf0 + 1) * H + y) * W + x0);
+      if (inside) {
+        if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+        if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+      }
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
-        const int x = x0 + p;
-        const int c0 = (r0 && x >= F0.x0 && x <= F0.x1) ? (int)((c0w >> (8 * p)) & 255) : 0;
-        const int c1 = (r1 && x >= F1.x0 && x <= F1.x1) ? (int)((c1w >> (8 * p)) & 255) : 0;
+        const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
         na0[p] = c0 >= 128 ? 255 : 0;
         m0[p] = dm.use_aa ? aa_byte(c0) : na0[p];
         m1[p] = dm.use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0);
@@ -628,20 +770,16 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
 #pragma unroll
       for (int p = 0; p < kPx; ++p) { ua0[p] = ua1[p] = un1[p] = 0; na0[p] = 0; }
       for (int k = 0; k < O.n_shapes; ++k) {
-        const int sf0 = (O.first_shape + k) * 2;
-        const DevShapeFrame& F0 = frames[sf0];
-        const DevShapeFrame& F1 = frames[sf0 + 1];
-        const bool r0 = inside && y >= F0.y0 && y <= F0.y1;
-        const bool r1 = inside && y >= F1.y0 && y <= F1.y1;
+        const uint8_t* c = cov + (size_t)(O.first_shape + k) * 2 * slot_bytes;
         uint32_t c0w = 0, c1w = 0;
-        if (r0) c0w = *reinterpret_cast<const uint32_t*>(cov + ((size_t)sf0 * H + y) * W + x0);
-        if (r1) c1w = *reinterpret_cast<const uint32_t*>(cov + ((size_t)(sf0 + 1) * H + y) * W + x0);
+        if (inside) {
+          if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+          if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+        }
         const bool additive = (O.additive >> k) & 1u;
 #pragma unroll
         for (int p = 0; p < kPx; ++p) {
-          const int x = x0 + p;
-          const int c0 = (r0 && x >= F0.x0 && x <= F0.x1) ? (int)((c0w >> (8 * p)) & 255) : 0;
-          const int c1 = (r1 && x >= F1.x0 && x <= F1.x1) ? (int)((c1w >> (8 * p)) & 255) : 0;
+          const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
           const int va0 = aa_byte(c0), va1 = aa_byte(c1);
           const int vn0 = c0 >= 128 ? 255 : 0, vn1 = c1 >= 128 ? 255 : 0;
           if (additive) {
@@ -666,8 +804,8 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
     if (any0) {
       // frame 0 texture: identity warp == the crop itself (DG:339-340)
-      const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (size_t)y * g.pitch + x0);
-      const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
+      const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
+      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
       for (int p = 0; p < kPx; ++p)
 #pragma unroll
@@ -690,7 +828,7 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
       for (int p = 0; p < kPx; ++p) {
         if (na0[p] == 255) {
           double ix = (double)(x0 + p), iy = (double)y;
-          const float save_x = (float)ix, save_y = (float)iy;
+          const float save_x = (float)(x0 + p), save_y = (float)y;
           xform(O.motion, ix, iy);
           fu[p] = (float)(ix - (double)save_x);
           fv[p] = (float)(iy - (double)save_y);

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -56,6 +57,15 @@ struct ofdg_ctx {
     DevBuf<int2> d_verts;
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
+    DevBuf<unsigned long long> d_tile_masks;
+    DevBuf<int4> d_items;
+    DevBuf<int4> d_obj_box;
+    int res_objects = 0;
+    hipEvent_t ev_uploaded = nullptr;
+    bool upload_pending = false;
+    hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records
+    bool compose_pending = false;
+    int* d_item_count = nullptr;
     int res_samples = 0, res_shapes = 0;
   };
   static constexpr int kSlots = 16;
@@ -64,14 +74,23 @@ struct ofdg_ctx {
   size_t h_stage_bytes = 0;
   hipEvent_t stage_free = nullptr;
   bool stage_pending = false;
-  DevBuf<uint8_t> d_cov;  // coverage workspace, shared by all slots (stream ordered)
+  // Coverage workspaces: two, used alternately, so that the preparation kernels of
+  // launch i+1 (internal stream) overlap the compose kernel of launch i (caller's stream).
+  DevBuf<uint8_t> d_cov2[2];
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t ev_prep_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_compose_done[2] = {nullptr, nullptr};
+  bool compose_pending[2] = {false, false};
+  int parity = 0;       // workspace of the next launch
+  int last_parity = 0;  // workspace the last launch used (debug read-back)
+  bool overlap = true;
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
   // profiling: ring of event sets, 4 events per launch (before geom / raster / compose, after compose)
   int profiling = 0;  // 0 off, 1 compose kernel only, 2 all three kernels
   std::vector<hipEvent_t> ev;
-  int ev_sets = 0;
-  long long ev_count = 0;
+  int ev_sets = 0, ev_stride = 1;
+  long long ev_count = 0, launch_count = 0;
   std::vector<ofdg_task> fw_tasks;
   std::vector<ofdg_blueprint> fw_bps;
 };
@@ -140,12 +159,25 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  // the raster kernel's cell arrays may exceed the default 64 KiB of dynamic LDS
-  const int lds = 2 * kBandRows * (params->width + 1) * (int)sizeof(int);
-  e = hipFuncSetAttribute((const void*)raster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) {
-    g_create_error = std::string("raster_kernel LDS attribute (is the gfx950 code object present?): ") + hipGetErrorString(e);
+  if ((e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return OFDG_EHIP;
+  }
+  for (int i = 0; i < 2; ++i)
+    if ((e = hipEventCreateWithFlags(&c->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_compose_done[i], hipEventDisableTiming)) != hipSuccess) {
+      g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
+      return OFDG_EHIP;
+    }
+  if (const char* v = std::getenv("OFDG_OVERLAP")) c->overlap = std::atoi(v) != 0;
+  // fail early (and loudly) if the gfx950 code object is not usable on this device
+  {
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, (const void*)compose_kernel);
+    if (e != hipSuccess) {
+      g_create_error = std::string("compose_kernel is not loadable (is the gfx950 code object present?): ") + hipGetErrorString(e);
+      return OFDG_EHIP;
+    }
   }
   *out = c.release();
   return OFDG_OK;
@@ -158,8 +190,19 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
+    sl.d_tile_masks.release(); sl.d_items.release(); sl.d_obj_box.release();
+    if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
-  c->d_cov.release();
+  for (int i = 0; i < 2; ++i) {
+    c->d_cov2[i].release();
+    if (c->ev_prep_done[i]) (void)hipEventDestroy(c->ev_prep_done[i]);
+    if (c->ev_compose_done[i]) (void)hipEventDestroy(c->ev_compose_done[i]);
+  }
+  for (auto& sl : c->slots) {
+    if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
+    if (sl.ev_composed) (void)hipEventDestroy(sl.ev_composed);
+  }
+  if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
@@ -261,23 +304,6 @@ int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps,
 static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
   const int W = c->prm.width, H = c->prm.height;
   const int n_sf = sl.res_shapes * 2;
-  hipEvent_t* ev = nullptr;
-  if (c->profiling && c->ev_sets > 0) ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
-  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], st));
-  if (n_sf > 0) {
-    hipLaunchKernelGGL(geom_kernel, dim3(n_sf), dim3(128), 0, st, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
-                       sl.d_frames.p, sl.d_verts.p, c->d_err);
-    HIP_OK(c, hipGetLastError());
-  }
-  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], st));
-  if (n_sf > 0) {
-    const int bands = (H + kBandRows - 1) / kBandRows;
-    const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
-    hipLaunchKernelGGL(raster_kernel, dim3(n_sf, bands), dim3(256), lds, st, sl.d_frames.p, n_sf, sl.d_verts.p, W, H,
-                       c->d_cov.p);
-    HIP_OK(c, hipGetLastError());
-  }
-  if (ev) HIP_OK(c, hipEventRecord(ev[2], st));
   RenderDims dm;
   dm.W = W; dm.H = H; dm.pool_w = c->pool_w; dm.pool_h = c->pool_h;
   dm.use_aa = c->prm.use_antialiasing ? 1 : 0;
@@ -285,10 +311,60 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
+  const int bands = (H + kBandRows - 1) / kBandRows;
+  hipEvent_t* ev = nullptr;
+  if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
+    ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
+  c->launch_count++;
+  // Preparation (geom -> bin -> raster) runs on the internal stream `ps`, compose on the
+  // caller's stream `st`.  prep(i) only waits for this slot's upload and for the compose
+  // that last read coverage workspace i % 2, so it overlaps compose(i - 1).
+  const int cb = c->parity;
+  c->parity ^= 1;
+  c->last_parity = cb;
+  hipStream_t ps = c->overlap ? c->prep_stream : st;
+  uint8_t* cov = c->d_cov2[cb].p;
+  if (c->overlap) {
+    if (sl.upload_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_uploaded, 0));
+    if (sl.compose_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
+    if (c->compose_pending[cb]) HIP_OK(c, hipStreamWaitEvent(ps, c->ev_compose_done[cb], 0));
+  }
+  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
+  // geom: outlines + bounding boxes (also zeroes the raster item counter)
+  hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(256), 0, ps, sl.d_shapes.p,
+                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, sl.d_obj_box.p, c->d_err, sl.d_item_count);
+  HIP_OK(c, hipGetLastError());
+  // bin: block -> object masks, raster work list
+  {
+    const int threads = dm.n_samples * bands * dm.tiles_x * 2 + n_sf * bands;
+    hipLaunchKernelGGL(bin_kernel, dim3((threads + 255) / 256), dim3(256), 0, ps, dm, sl.d_samples.p, sl.d_shapes.p,
+                       sl.d_obj_box.p, sl.d_tile_masks.p, sl.d_items.p, sl.d_item_count);
+    HIP_OK(c, hipGetLastError());
+  }
+  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
+  {
+    static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
+    hipLaunchKernelGGL(raster_kernel, dim3(rgrid), dim3(256), 0, ps, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
+                       sl.d_verts.p, W, H, cov, sl.d_obj_box.p, sl.res_objects);
+    HIP_OK(c, hipGetLastError());
+  }
+  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[2], ps));
+  if (c->overlap) {
+    HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
+    HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
+  }
+  if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
-                     sl.d_objects.p, sl.d_frames.p, c->d_cov.p, c->pool, d_img0, d_img1, d_flow);
+                     sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow);
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
+  if (c->overlap) {
+    HIP_OK(c, hipEventRecord(c->ev_compose_done[cb], st));
+    c->compose_pending[cb] = true;
+    if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
+    HIP_OK(c, hipEventRecord(sl.ev_composed, st));
+    sl.compose_pending = true;
+  }
   return OFDG_OK;
 }
 
@@ -304,13 +380,28 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   if (rc != OFDG_OK) return rc;
   const RealizedBatch& B = sl.batch;
   const size_t n_shapes = B.shapes.size(), n_obj = B.objects.size();
-  const int W = c->prm.width, H = c->prm.height;
   HIP_OK(c, sl.d_shapes.reserve(n_shapes));
   HIP_OK(c, sl.d_frames.reserve(n_shapes * 2));
   HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
-  if (n_shapes * 2 * (size_t)W * H + 16 > c->d_cov.cap) {
-    HIP_OK(c, hipDeviceSynchronize());  // other slots' launches may still use the workspace
-    HIP_OK(c, c->d_cov.reserve(n_shapes * 2 * (size_t)W * H + 16));
+  {
+    const int W = c->prm.width, H = c->prm.height;
+    const size_t need_cov = n_shapes * 2 * (size_t)W * H + 16;
+    if (need_cov > c->d_cov2[0].cap) {
+      HIP_OK(c, hipDeviceSynchronize());
+      HIP_OK(c, c->d_cov2[0].reserve(need_cov));
+      HIP_OK(c, c->d_cov2[1].reserve(need_cov));
+    }
+    const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
+    (void)tiles;
+    HIP_OK(c, sl.d_tile_masks.reserve((size_t)n_tasks * ((H + kBandRows - 1) / kBandRows) * ((W + kTileW - 1) / kTileW) * 2));
+    HIP_OK(c, sl.d_items.reserve(n_shapes * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
+    if (n_obj * 2 > sl.d_obj_box.cap) {
+      HIP_OK(c, hipDeviceSynchronize());
+      HIP_OK(c, sl.d_obj_box.reserve(n_obj * 2));
+      // emptied once here; afterwards raster_kernel re-empties the boxes every launch
+      HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
+    }
+    if (!sl.d_item_count) HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
   }
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n_tasks));
@@ -332,8 +423,12 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   HIP_OK(c, hipMemcpyAsync(sl.d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipEventRecord(c->stage_free, st));
   c->stage_pending = true;
+  if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
+  HIP_OK(c, hipEventRecord(sl.ev_uploaded, st));
+  sl.upload_pending = true;
   sl.res_samples = n_tasks;
   sl.res_shapes = (int)n_shapes;
+  sl.res_objects = (int)n_obj;
   return OFDG_OK;
 }
 
@@ -387,6 +482,7 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
 int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   if (!c) return OFDG_EINVAL;
   HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
+  HIP_OK(c, hipStreamSynchronize(c->prep_stream));
   uint32_t e = 0;
   HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
   if (e) {
@@ -423,23 +519,30 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   ofdg_ctx::Slot& sl = c->slots[0];
   HIP_OK(c, sl.d_frames.reserve(2));
   HIP_OK(c, sl.d_verts.reserve(2 * kMaxVerts));
-  HIP_OK(c, c->d_cov.reserve((size_t)2 * W * H + 16));
+  HIP_OK(c, c->d_cov2[0].reserve((size_t)2 * W * H + 16));
   HIP_OK(c, hipMemcpy(sl.d_frames.p, &f, sizeof(f), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_verts.p, v.data(), sizeof(int2) * kMaxVerts, hipMemcpyHostToDevice));
-  HIP_OK(c, hipMemset(c->d_cov.p, 0xAB, (size_t)W * H));  // poison: only the bbox may be read back
+  HIP_OK(c, hipMemset(c->d_cov2[0].p, 0xAB, (size_t)W * H));  // poison: every byte must be written
   const int bands = (H + kBandRows - 1) / kBandRows;
-  const size_t lds = (size_t)2 * kBandRows * (W + 1) * sizeof(int);
-  hipLaunchKernelGGL(raster_kernel, dim3(1, bands), dim3(256), lds, 0, sl.d_frames.p, 1, sl.d_verts.p, W, H, c->d_cov.p);
+  std::vector<int4> items;
+  for (int b = 0; b < bands; ++b)
+    for (int cx = 0; cx < W; cx += kChunkW) items.push_back(make_int4(0, b, cx, std::min(cx + kChunkW - 1, W - 1)));
+  const int n_items = (int)items.size();
+  HIP_OK(c, sl.d_items.reserve(items.size()));
+  if (sl.d_obj_box.cap == 0) {
+    HIP_OK(c, sl.d_obj_box.reserve(1));
+    HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
+  }
+  if (!sl.d_item_count) HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
+  HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(raster_kernel, dim3(64), dim3(256), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
+                     W, H, c->d_cov2[0].p, sl.d_obj_box.p, 0);
   HIP_OK(c, hipGetLastError());
-  std::vector<uint8_t> tmp((size_t)W * H);
-  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p, tmp.size(), hipMemcpyDeviceToHost));
-  std::memset(coverage_host, 0, tmp.size());
-  for (int y = y0; y <= y1; ++y)
-    for (int x = x0; x <= x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
+  HIP_OK(c, hipMemcpy(coverage_host, c->d_cov2[0].p, (size_t)W * H, hipMemcpyDeviceToHost));
   for (auto& s2 : c->slots) s2.res_samples = 0;  // the workspaces no longer hold a rendered batch
   return OFDG_OK;
 }
-
 int ofdg_debug_num_shapes(ofdg_ctx* c, int sample) {
   if (!c || c->slots[0].res_samples <= 0 || sample < 0 || sample >= (int)c->slots[0].batch.samples.size()) return OFDG_EINVAL;
   return c->slots[0].batch.samples[sample].n_shapes;
@@ -456,11 +559,20 @@ int ofdg_debug_coverage(ofdg_ctx* c, int sample, int shape, int frame, uint8_t* 
   DevShapeFrame f;
   HIP_OK(c, hipMemcpy(&f, c->slots[0].d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
   std::vector<uint8_t> tmp((size_t)W * H);
-  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov.p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov2[c->last_parity].p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
   std::memset(coverage_host, 0, tmp.size());
   for (int y = f.y0; y <= f.y1; ++y)
     for (int x = f.x0; x <= f.x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
   return OFDG_OK;
+}
+
+// number of raster work items of the last launch of slot 0 (diagnostics)
+int ofdg_debug_item_count(ofdg_ctx* c) {
+  if (!c || !c->slots[0].d_item_count) return OFDG_EINVAL;
+  int n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return OFDG_EHIP;
+  if (hipMemcpy(&n, c->slots[0].d_item_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return OFDG_EHIP;
+  return n;
 }
 
 int ofdg_set_profiling(ofdg_ctx* c, int mode) {
@@ -468,6 +580,8 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
   HIP_OK(c, hipDeviceSynchronize());
   c->profiling = mode;
   c->ev_count = 0;
+  c->launch_count = 0;
+  c->ev_stride = (mode == 1) ? 4 : 1;  // mode 1 samples every 4th launch: keeps the event cost out of throughput runs
   if (mode && c->ev.empty()) {
     c->ev_sets = 256;
     c->ev.resize((size_t)c->ev_sets * 4);

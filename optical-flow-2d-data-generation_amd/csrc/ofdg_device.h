@@ -11,6 +11,8 @@ constexpr int kMaxVerts = 1024;     // flattened outline capacity per (shape, fr
 constexpr int kCurveMaxPts = 96;    // points one curve3 may flatten to
 constexpr int kCurveMaxDepth = 16;  // DFS stack depth for curve3 subdivision
 constexpr int kBandRows = 8;        // scanlines one raster workgroup accumulates in LDS
+constexpr int kMaxFgObjects = 64;   // foreground objects per sample (bits of a tile mask)
+constexpr int kRasterGrid = 2048;   // persistent raster workgroups
 
 // error bits raised by kernels (device word, read by ofdg_synchronize)
 constexpr uint32_t kErrVertCapacity = 1u;   // outline has more than kMaxVerts vertices
@@ -35,7 +37,8 @@ struct DevShape {
   int32_t n_seg;
   int32_t sample;  // batch slot
   int32_t deform;  // mode 9: frame-1 mask is re-sampled through warp slot `deform-1`
-  int32_t pad[2];
+  int32_t object;  // index of the owning DevObject in the batch
+  int32_t pad;
 };
 
 // Produced by the geom kernel for each (shape, frame).

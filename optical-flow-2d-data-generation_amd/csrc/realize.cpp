@@ -24,7 +24,7 @@ Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H
   return r;
 }
 
-int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample,
+int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object,
                std::vector<DevShape>* shapes, std::string* msg) {
   if (p.obj_type != OFDG_OBJ_ELLIPSE && p.obj_type != OFDG_OBJ_POLYGON) {
     *msg = "(RealizeObjectBlueprint) Bad object type, or not intended in this mode";  // DataGenerator.cpp:1143
@@ -38,6 +38,7 @@ int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_
   s.rx = p.ellipse_scale_x;
   s.ry = p.ellipse_scale_y;
   s.sample = sample;
+  s.object = object;
   if (p.obj_type == OFDG_OBJ_POLYGON) {
     if (p.n_segments < 1 || p.n_segments > kMaxSegments) {
       *msg = "polygon blueprint with a segment count outside [1, 20]";
@@ -83,6 +84,10 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         task.first_object < 0 || task.first_object + task.n_objects > n_bps) {
       *msg = "task refers to blueprints outside the array";
       return OFDG_EINVAL;
+    }
+    if (task.n_objects > kMaxFgObjects) {
+      *msg = "more than 64 foreground objects in one sample";
+      return OFDG_ECAPACITY;
     }
     DevSample smp;
     smp.first_object = (int32_t)out->objects.size();
@@ -137,14 +142,14 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         o.n_shapes = p.n_components;
         for (int k = 0; k < p.n_components; ++k) {
           const ofdg_blueprint& c = bps[p.first_component + k];
-          int rc = push_shape(cfg, c, bg_motion, t, &out->shapes, msg);
+          int rc = push_shape(cfg, c, bg_motion, t, (int)out->objects.size(), &out->shapes, msg);
           if (rc != OFDG_OK) return rc;
           if (c.is_additive_component) o.additive |= (1u << k);
         }
       } else {
         o.kind = 1;
         o.n_shapes = 1;
-        int rc = push_shape(cfg, p, bg_motion, t, &out->shapes, msg);
+        int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), &out->shapes, msg);
         if (rc != OFDG_OK) return rc;
       }
       out->objects.push_back(o);

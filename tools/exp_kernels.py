@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Developer experiment: per-kernel times of the bench workload under variants
+(OFDG_VARIANT=0 fused raster / 1 coverage slots), with and without foreground objects."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+W, H, MODE, B = 512, 384, int(os.environ.get("MODE", "5")), 32
+NOBJ = int(os.environ.get("NOBJ", "16"))
+g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=MODE, num_objects=NOBJ))
+g.pool_synthetic(1000, 1024, 768, 2024)
+hs = ofdg.HostSampler(MODE, W, H, NOBJ)
+st = torch.cuda.current_stream().cuda_stream
+NS = 8
+for slot in range(NS):
+    tasks, bps, n = hs.next(B, cap=B * 64)
+    if os.environ.get("BGONLY"):
+        for t in tasks: t.n_objects = 0
+    g.upload_slot(slot, tasks, B, bps, n, st)
+i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+for i in range(20): g.render_slot(i % NS, i0, i1, fl, st)
+g.synchronize(st)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(200): g.render_slot(i % NS, i0, i1, fl, st)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+g.set_profiling(2)
+for i in range(64): g.render_slot(i % NS, i0, i1, fl, st)
+g.synchronize(st)
+print("variant=%s bgonly=%s mode=%d step=%.1f us  geom=%.1f raster=%.1f compose=%.1f us  -> %.0f samples/s" % (
+    os.environ.get("OFDG_VARIANT", "0"), bool(os.environ.get("BGONLY")), MODE, dt * 1e6,
+    g.kernel_ms("geom") * 1e3, g.kernel_ms("raster") * 1e3, g.kernel_ms("compose") * 1e3, B / dt))
+import ctypes
+g.render_slot(0, i0, i1, fl, st); g.synchronize(st)
+print("raster items in slot 0:", ofdg.lib().ofdg_debug_item_count(g.h))

@@ -324,6 +324,61 @@ struct CellAcc {
   }
 };
 
+// ---- 32-bit fast path ---------------------------------------------------------------
+// For edges shorter than 8192 px horizontally and 1024 px vertically every product in
+// the closed forms fits 32 bits, and all floor divisions can use a float reciprocal
+// followed by an exact integer correction.
+// floor(num / den), den >= 1, |true quotient| <= 4096: one estimate, one +-1 fix.
+__device__ __forceinline__ int fdiv_small(int num, int den, float rcp) {
+  int q = (int)floorf((float)num * rcp);
+  const int r = num - q * den;
+  if (r < 0) --q;
+  else if (r >= den) ++q;
+  return q;
+}
+// floor(num / den), den >= 1, |num| < 2^29: two-step estimate (the first remainder is
+// small enough for the second estimate to be within one of the truth).
+__device__ __forceinline__ int fdiv_big(int num, int den, float rcp) {
+  const int q0 = (int)floorf((float)num * rcp);
+  const int r0 = num - q0 * den;
+  return q0 + fdiv_small(r0, den, rcp);
+}
+
+// render_hline in closed form, both directions in one code path.
+template <class Acc>
+__device__ __forceinline__ void hline32(const Acc& acc, int r, int xa, int ya, int xb, int yb) {
+  if (ya == yb) return;
+  const int exa = xa >> 8, exb = xb >> 8;
+  const int fxa = xa & 255, fxb = xb & 255;
+  const int Dy = yb - ya;
+  if (exa == exb) {
+    acc.add(r, exa, Dy, (fxa + fxb) * Dy);
+    return;
+  }
+  const int lo = min(exa, exb), hi = max(exa, exb);
+  if (hi < acc.X0) { acc.add(r, acc.X0 - 1, Dy, 0); return; }  // entirely left: only its cover counts
+  if (lo > acc.X1) return;                                      // entirely right: no effect
+  const bool right = xb > xa;
+  const int adx = right ? xb - xa : xa - xb;
+  const float rcp = __frcp_rn((float)adx);
+  const int m = hi - lo;
+  const int f0 = right ? 256 - fxa : fxa;
+  const int j_lo = right ? max(0, acc.X0 - exa) : max(0, exa - acc.X1);
+  const int j_hi = right ? min(m, acc.X1 - exa) : min(m, exa - acc.X0);
+  // y where the hline enters cell j (j = 1..m): ya + floor((f0 + 256 (j-1)) Dy / adx)
+  int yprev = (j_lo == 0) ? ya : ya + fdiv_small((f0 + 256 * (j_lo - 1)) * Dy, adx, rcp);
+  if (right && j_lo > 0) acc.add(r, acc.X0 - 1, yprev - ya, 0);  // cells left of the range
+  for (int j = j_lo; j <= j_hi; ++j) {
+    const int ynext = (j == m) ? yb : ya + fdiv_small((f0 + 256 * j) * Dy, adx, rcp);
+    const int d = ynext - yprev;
+    const int fin = (j == 0) ? fxa : (right ? 0 : 256);
+    const int fout = (j == m) ? fxb : (right ? 256 : 0);
+    acc.add(r, right ? exa + j : exa - j, d, (fin + fout) * d);
+    yprev = ynext;
+  }
+  if (!right && j_hi < m) acc.add(r, acc.X0 - 1, yb - yprev, 0);  // what remains lies left of the range
+}
+
 // rasterizer_cells_aa::render_hline(ey, xa, ya, xb, yb) in closed form.
 template <class Acc>
 __device__ __forceinline__ void hline(const Acc& acc, int r, int xa, int ya, int xb, int yb) {
@@ -393,6 +448,32 @@ template <class Acc>
 __device__ __forceinline__ void edge_scanline(const Acc& acc, int r, int y, int x1, int y1, int x2, int y2) {
   const int ey1 = y1 >> 8, ey2 = y2 >> 8;
   const int fy1 = y1 & 255, fy2 = y2 & 255;
+  {
+    const int dxi = x2 - x1, dyi = y2 - y1;
+    const int adx = dxi < 0 ? -dxi : dxi, ady = dyi < 0 ? -dyi : dyi;
+    if (adx < (1 << 21) && ady < (1 << 18)) {  // 32-bit fast path (virtually every edge)
+      if (ey1 == ey2) {
+        if (y == ey1) hline32(acc, r, x1, fy1, x2, fy2);
+        return;
+      }
+      const bool up = dyi < 0;
+      if (y < min(ey1, ey2) || y > max(ey1, ey2)) return;
+      const int k = up ? ey1 - y : y - ey1;
+      const bool last = (y == ey2);
+      const float rcp = __frcp_rn((float)ady);
+      // X(k) = x1 + floor((base + 256 (k-1)) dx / |dy|)
+      //      = x1 + d1 + (k-1) lift + floor((m1 + (k-1) rem) / |dy|)   (exact identity)
+      const int p1 = (up ? fy1 : 256 - fy1) * dxi;
+      const int d1 = fdiv_big(p1, ady, rcp), m1 = p1 - d1 * ady;
+      const int lift = fdiv_big(256 * dxi, ady, rcp), rem = 256 * dxi - lift * ady;
+      const int xa = (k == 0) ? x1 : x1 + d1 + (k - 1) * lift + fdiv_small(m1 + (k - 1) * rem, ady, rcp);
+      const int xb = last ? x2 : x1 + d1 + k * lift + fdiv_small(m1 + k * rem, ady, rcp);
+      const int ya = (k == 0) ? fy1 : (up ? 256 : 0);
+      const int yb = last ? fy2 : (up ? 0 : 256);
+      hline32(acc, r, xa, ya, xb, yb);
+      return;
+    }
+  }
   if (ey1 == ey2) {
     if (y == ey1) hline(acc, r, x1, fy1, x2, fy2);
     return;
@@ -549,6 +630,17 @@ __device__ __forceinline__ int div255(int a) { return (a + 1 + (a >> 8)) >> 8; }
 // CImg::draw_image(sprite, mask, 1, 255): d = floor((m*s + (255-m)*d) / 255)
 __device__ __forceinline__ int blend(int d, int s, int m) { return div255(m * s + (255 - m) * d); }
 
+// The same blend on a packed B | G<<8 | R<<16 pixel: B and R share one multiply-add
+// (16-bit lanes: m*s + (255-m)*d <= 65025 never carries), G goes alone.
+__device__ __forceinline__ uint32_t blend_px(uint32_t d, uint32_t s, uint32_t m) {
+  const uint32_t im = 255u - m;
+  uint32_t rb = m * (s & 0x00FF00FFu) + im * (d & 0x00FF00FFu);
+  uint32_t g = m * ((s >> 8) & 255u) + im * ((d >> 8) & 255u);
+  rb = ((rb + 0x00010001u + ((rb >> 8) & 0x00FF00FFu)) >> 8) & 0x00FF00FFu;  // floor(x / 255) per lane
+  g = (g + 1u + (g >> 8)) >> 8;
+  return rb | (g << 8);
+}
+
 // MovingObjectComposite::renderMasks, strict fp32 (DG:606, 626)
 __device__ __forceinline__ int comp_add(int u, int v) {
   const float fu = __fdiv_rn((float)u, 255.f), fv = __fdiv_rn((float)v, 255.f);
@@ -565,13 +657,19 @@ struct RowDDA {
   int x1, lx, rx;  // start, lft, rem (rem in [1, n])
   int y1, ly, ry;
 };
-__device__ __forceinline__ void dda_setup(int a, int b, int n, int& lft, int& rem) {
+__device__ __forceinline__ void dda_setup(int a, int b, int n, int nshift, int& lft, int& rem) {
   const int D = b - a;
-  lft = D / n;
-  rem = D % n;
-  if (rem <= 0) { rem += n; lft--; }
+  if (nshift >= 0) {  // n is a power of two (wave-uniform): floor quotient / remainder by shifts
+    const int q = D >> nshift, r = D & (n - 1);
+    lft = r > 0 ? q : q - 1;  // dda2_line_interpolator: rem in [1, n]
+    rem = r > 0 ? r : n;
+  } else {
+    lft = D / n;
+    rem = D % n;
+    if (rem <= 0) { rem += n; lft--; }
+  }
 }
-__device__ __forceinline__ RowDDA make_row(const Mat& inv, int row, int len) {
+__device__ __forceinline__ RowDDA make_row(const Mat& inv, int row, int len, int nshift) {
   RowDDA R;
   double tx = 0 + 0.5, ty = row + 0.5;
   xform(inv, tx, ty);
@@ -580,8 +678,8 @@ __device__ __forceinline__ RowDDA make_row(const Mat& inv, int row, int len) {
   tx = 0 + 0.5 + len; ty = row + 0.5;
   xform(inv, tx, ty);
   const int x2 = iround_d(tx * 256.0), y2 = iround_d(ty * 256.0);
-  dda_setup(R.x1, x2, len, R.lx, R.rx);
-  dda_setup(R.y1, y2, len, R.ly, R.ry);
+  dda_setup(R.x1, x2, len, nshift, R.lx, R.rx);
+  dda_setup(R.y1, y2, len, nshift, R.ly, R.ry);
   return R;
 }
 // value of the interpolator after i increments
@@ -591,8 +689,17 @@ __device__ __forceinline__ int dda_at(int y1, int lft, int rem, int n, int nshif
   return y1 + i * lft + q - 1;
 }
 __device__ __forceinline__ int wrap_reflect(int v, int size, int size2, int mask2, int& raw) {
-  int m = (mask2 >= 0) ? (v & mask2) : (v % size2);
-  if (m < 0) m += size2;
+  int m;
+  if (mask2 >= 0) {  // power-of-two period (wave-uniform)
+    m = v & mask2;
+  } else if ((unsigned)(v + size2) < 3u * (unsigned)size2) {  // within one period of the image: no division
+    m = v;
+    if (m < 0) m += size2;
+    if (m >= size2) m -= size2;
+  } else {
+    m = v % size2;
+    if (m < 0) m += size2;
+  }
   raw = m;
   return m >= size ? size2 - 1 - m : m;
 }
@@ -646,7 +753,9 @@ __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__
 // touched tile, zero outside the outlines).
 // Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799,
 // computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
-__global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSample* __restrict__ samples,
+// At most 4 waves per SIMD: compose is bandwidth-bound well before that, and the spare
+// registers let the (latency-bound) preparation kernels of the next batch co-reside.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose_kernel(RenderDims dm, const DevSample* __restrict__ samples,
                                                       const DevObject* __restrict__ objects,
                                                       const unsigned long long* __restrict__ tile_masks,
                                                       const uint8_t* __restrict__ cov,
@@ -685,7 +794,7 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
   }
   unsigned long long omask = mask0 | mask1;
 
-  int f0[3][kPx], f1[3][kPx];
+  uint32_t px0[kPx], px1[kPx];  // frames, packed B | G<<8 | R<<16
   float fu[kPx], fv[kPx];
 
   // ---- background (object 0): masks are all 255, so frames start as its textures ----
@@ -703,17 +812,13 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
       const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
       const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
-      const RowDDA R = make_row(B.tex_inv, yy, g.tw);
+      const RowDDA R = make_row(B.tex_inv, yy, g.tw, g.nshift);
       // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
       const double by = (double)(y + H / 2) + (double)(-H);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
-        const uint32_t t1 = sample_bilinear(tex, g, R, xx + p);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          f0[c][p] = (tt[p] >> (8 * c)) & 255;
-          f1[c][p] = (t1 >> (8 * c)) & 255;
-        }
+        px0[p] = tt[p] & 0x00FFFFFFu;
+        px1[p] = sample_bilinear(tex, g, R, xx + p);
         double ix = (double)(x0 + p + W / 2), iy = by;
         const float save_x = (float)(x0 + p + W / 2), save_y = (float)(y + H / 2);
         ix = ix + (double)(-W);
@@ -726,8 +831,7 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         fu[p] = fv[p] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) f0[c][p] = f1[c][p] = 0;
+        px0[p] = px1[p] = 0;
       }
     }
   }
@@ -807,18 +911,14 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
       const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
       const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
-      for (int p = 0; p < kPx; ++p)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) f0[c][p] = blend(f0[c][p], (tt[p] >> (8 * c)) & 255, m0[p]);
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
     }
     if (any1) {
-      const RowDDA R = make_row(O.tex_inv, y, W);
+      const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         if (m1[p]) {
-          const uint32_t t1 = sample_bilinear(tex, g, R, x0 + p);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) f1[c][p] = blend(f1[c][p], (t1 >> (8 * c)) & 255, m1[p]);
+          px1[p] = blend_px(px1[p], sample_bilinear(tex, g, R, x0 + p), (uint32_t)m1[p]);
         }
       }
     }
@@ -844,8 +944,10 @@ __global__ __launch_bounds__(256) void compose_kernel(RenderDims dm, const DevSa
   const size_t o = (size_t)y * W + x0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    f32x4 a = {(float)f0[c][0], (float)f0[c][1], (float)f0[c][2], (float)f0[c][3]};
-    f32x4 b = {(float)f1[c][0], (float)f1[c][1], (float)f1[c][2], (float)f1[c][3]};
+    f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
+               (float)((px0[2] >> (8 * c)) & 255u), (float)((px0[3] >> (8 * c)) & 255u)};
+    f32x4 b = {(float)((px1[0] >> (8 * c)) & 255u), (float)((px1[1] >> (8 * c)) & 255u),
+               (float)((px1[2] >> (8 * c)) & 255u), (float)((px1[3] >> (8 * c)) & 255u)};
     __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(img0 + ((size_t)s * 3 + c) * plane + o));
     __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(img1 + ((size_t)s * 3 + c) * plane + o));
   }
@@ -915,7 +1017,8 @@ __global__ void tables_kernel(uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tb
   const int u = i >> 8, v = i & 255;
   add_tbl[i] = (uint8_t)comp_add(u, v);
   sub_tbl[i] = (uint8_t)comp_sub(u, v);
-  blend_tbl[i] = (uint8_t)blend(u, s_fixed, v);  // d = u, m = v
+  blend_tbl[i] = (uint8_t)((blend_px((uint32_t)u * 0x00010101u, (uint32_t)s_fixed * 0x00010101u, (uint32_t)v) >> 16) & 255u);  // d = u, m = v (R lane)
+  if (((blend_px((uint32_t)u * 0x00010101u, (uint32_t)s_fixed * 0x00010101u, (uint32_t)v)) & 255u) != (uint32_t)blend(u, s_fixed, v) || ((blend_px((uint32_t)u * 0x00010101u, (uint32_t)s_fixed * 0x00010101u, (uint32_t)v) >> 8) & 255u) != (uint32_t)blend(u, s_fixed, v)) blend_tbl[i] = 0xEE;  // all three lanes must agree with the scalar form
   if (i < 256) aa_tbl[i] = (uint8_t)aa_byte(i);
 }
 

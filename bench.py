@@ -30,31 +30,32 @@ ALG_BYTES_PER_SAMPLE = 38 * W * H       # 32 B/px written (8 fp32 planes) + 6 B/
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(ofdg, gen, tasks, bps, n_bps, budget_s=15.0):
+def cpu_baseline(ofdg, gen, budget_s=15.0):
     """The oracle (CPU restatement of the reference path, per-object full-frame work like
-    the reference) timed on this host's cores: first_level_threads = all cores,
-    second_level_threads = 1 (reference threading, DataGenerator.cpp:1023-1027)."""
+    the reference) timed on this host's cores with the reference's threading: one sample
+    worker per core (first_level_threads = cores, second_level_threads = 1,
+    DataGenerator.cpp:1023-1027).  A bounded sample of the same workload."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as oracle
     cores = os.cpu_count() or 1
+    n = max(cores, 8)  # one task per worker thread and round
+    tasks, bps, n_bps = ofdg.HostSampler(MODE, W, H, NOBJ).next(n, cap=n * 64)
     sub = np.stack([gen.pool_download(i) for i in range(4)])  # tex_id % 4: same work, small host pool
     prm = oracle.default_params(W, H, MODE, 1, 1, NOBJ)
-    n = min(cores, BATCH)
     t0 = time.perf_counter()
     oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
-    dt = time.perf_counter() - t0
+    first = time.perf_counter() - t0
     done = n
-    # scale the sample to the budget (whole multiples of the first chunk)
-    reps = int(max(0, min((budget_s - dt) / max(dt, 1e-6), 64)))
+    reps = int(max(0, min((budget_s - first) / max(first, 1e-6), 64)))
     for _ in range(reps):
         oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
         done += n
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d samples of this workload (mode %d, %dx%d, %d objects; 4-texture host pool subset), "
-                      "oracle/ restatement with the reference's per-object full-frame work, %d threads" %
-                      (done, MODE, W, H, NOBJ, cores)}
+            "sample": "%d samples of this workload (mode %d, %dx%d, %d objects; 4-texture host pool subset) in %.1f s; "
+                      "oracle/ restatement with the reference's per-object full-frame work, %d worker threads" %
+                      (done, MODE, W, H, NOBJ, dt, cores)}
 
 
 def main():
@@ -162,7 +163,7 @@ def main():
             "host_ref_sampler_samples_per_s": host_sampler_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ofdg, gen, first[0], first[1], first[2])
+            out["cpu_baseline"] = cpu_baseline(ofdg, gen)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

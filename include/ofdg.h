@@ -190,6 +190,8 @@ int ofdg_debug_rasterize(ofdg_ctx* ctx, const double* xy, int n_vertices,
 int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
                         uint8_t* coverage_host);
 int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
+/* Number of raster work items the last launch of slot 0 produced (diagnostics). */
+int ofdg_debug_item_count(ofdg_ctx* ctx);
 /* Per-kernel device time (ms) of the last render, measured with HIP events on
  * the launch stream when profiling is enabled. names: "geom","raster","compose". */
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract

@@ -71,7 +71,7 @@ EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
     "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
-    "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_tables",
+    "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",

@@ -794,6 +794,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   unsigned long long omask = mask0 | mask1;
 
+  const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
+  const size_t slot_bytes = (size_t)W * H;
+  // Coverage of the next simple object is requested one iteration ahead, so its memory
+  // round trip overlaps the texture fetches and blends of the current object.
+  uint32_t nc0 = 0, nc1 = 0;
+  auto prefetch = [&](unsigned long long m) {
+    nc0 = 0; nc1 = 0;
+    if (m == 0) return;
+    const int oj = __ffsll((long long)m);
+    const DevObject& N = objs[oj];
+    if (N.kind != 1 || !inside) return;
+    const uint8_t* c = cov + (size_t)N.first_shape * 2 * slot_bytes;
+    if ((mask0 >> (oj - 1)) & 1ull) nc0 = *reinterpret_cast<const uint32_t*>(c + pix);
+    if ((mask1 >> (oj - 1)) & 1ull) nc1 = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+  };
+  prefetch(omask);
+
   uint32_t px0[kPx], px1[kPx];  // frames, packed B | G<<8 | R<<16
   float fu[kPx], fv[kPx];
 
@@ -843,8 +860,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
   g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
   g.pitch = dm.pool_w;
-  const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
-  const size_t slot_bytes = (size_t)W * H;
 
   while (omask) {
     const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
@@ -855,12 +870,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int m0[kPx], m1[kPx];   // blending masks for the two frames
     int na0[kPx];           // thresholded frame-0 mask (index image)
     if (O.kind == 1) {
-      const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
-      uint32_t c0w = 0, c1w = 0;
-      if (inside) {
-        if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
-        if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
-      }
+      const uint32_t c0w = nc0, c1w = nc1;
+      prefetch(omask);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
@@ -900,27 +911,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         m0[p] = dm.use_aa ? ua0[p] : na0[p];
         m1[p] = dm.use_aa ? ua1[p] : un1[p];
       }
+      prefetch(omask);
     }
 
     const int any0 = m0[0] | m0[1] | m0[2] | m0[3];
     const int any1 = m1[0] | m1[1] | m1[2] | m1[3];
     const int anyn = na0[0] | na0[1] | na0[2] | na0[3];
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
+    // issue every texture fetch of this object before the first blend waits on one
+    uint4 q0 = make_uint4(0, 0, 0, 0);
+    uint32_t t1[kPx] = {0, 0, 0, 0};
+    if (any0)  // frame 0 texture: identity warp == the crop itself (DG:339-340)
+      q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
+    if (any1) {
+      const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) t1[p] = sample_bilinear(tex, g, R, x0 + p);
+    }
     if (any0) {
-      // frame 0 texture: identity warp == the crop itself (DG:339-340)
-      const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
       const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
       for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
     }
     if (any1) {
-      const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
 #pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        if (m1[p]) {
-          px1[p] = blend_px(px1[p], sample_bilinear(tex, g, R, x0 + p), (uint32_t)m1[p]);
-        }
-      }
+      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (uint32_t)m1[p]);  // m == 0 leaves the pixel as is
     }
     if (anyn) {
       // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns

@@ -254,3 +254,75 @@ def test_full_size_properties(ofdg):
     d2x = f[:, :, 2:] - 2 * f[:, :, 1:-1] + f[:, :, :-2]
     d2y = f[:, 2:, :] - 2 * f[:, 1:-1, :] + f[:, :-2, :]
     assert float(d2x.abs().max()) < 1e-4 and float(d2y.abs().max()) < 1e-4
+
+
+LAYER_PROTOTXT = '''
+layer {
+  name: "gen"
+  type: "DataGeneration"
+  top: "a" top: "b" top: "f"
+  data_param { batch_size: 3 prefetch: 2 }
+  data_generation_param { mode: 7 texture_dbases: "%s" width: 128 height: 96 }
+}
+'''
+
+
+def test_layer_surface_forward_matches_oracle(ofdg, oracle, tmp_path):
+    """The Caffe-layer-shaped host class: prototxt -> LayerSetUp -> Forward, with a texture
+    list file of binary PPMs; two consecutive Forward() calls continue the 45 streams."""
+    rng = np.random.RandomState(5)
+    paths = []
+    pool = []
+    for i in range(3):
+        rgb = rng.randint(0, 256, (192, 256, 3)).astype(np.uint8)
+        p = tmp_path / ("tex%d.ppm" % i)
+        with open(p, "wb") as f:
+            f.write(b"P6\n# synthetic\n256 192\n255\n")
+            f.write(rgb.tobytes())
+        paths.append(str(p))
+        pool.append(np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))  # planar B, G, R
+    lst = tmp_path / "database.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
+    assert layer.type() == "DataGeneration"
+    s = oracle.Sampler(7, 128, 96)
+    prm = oracle.default_params(128, 96, 7)
+    for _ in range(2):
+        a, b, f = layer.Forward()
+        assert tuple(a.shape) == (3, 3, 96, 128) and tuple(f.shape) == (3, 2, 96, 128)
+        tasks, bps, n = s.next(3)
+        e0, e1, ef = oracle.render(prm, tasks, 3, bps, n, np.stack(pool))
+        assert np.array_equal(a.cpu().numpy(), e0) and np.array_equal(b.cpu().numpy(), e1)
+        assert ulp_diff(f.cpu().numpy(), ef).max() == 0
+    layer.close()
+    # the reference drops a last line without trailing newline (DataGenerator.cpp:124-126)
+    lst.write_text("\n".join(paths))
+    layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
+    layer.close()
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.DataGenerationLayer(LAYER_PROTOTXT % (tmp_path / "missing.txt"))
+    assert e.value.code == ofdg.ETEXTURES and "Could not open texture collection" in str(e.value)
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.DataGenerationLayer((LAYER_PROTOTXT % lst).replace("mode: 7", "mode: 77"))
+    assert e.value.code == ofdg.EBADMODE
+
+
+def test_forward_shards_across_ranks(ofdg, oracle):
+    """ofdg_forward with rank/world_size: rank r renders block r of every B*world tasks."""
+    W, H, B = 128, 96, 2
+    s = oracle.Sampler(5, W, H)
+    tasks, bps, n = s.next(B * 2)
+    outs = []
+    for rank in range(2):
+        g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, batch_size=B, rank=rank, world_size=2))
+        g.pool_synthetic(3, 256, 192, 9)
+        pool = g.pool_download_all()
+        i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+        g.forward(i0, i1, fl)
+        g.synchronize()
+        outs.append((i0.cpu().numpy(), i1.cpu().numpy(), fl.cpu().numpy()))
+    e0, e1, ef = oracle.render(oracle.default_params(W, H, 5), tasks, B * 2, bps, n, pool)
+    for rank in range(2):
+        assert np.array_equal(outs[rank][0], e0[rank * B:(rank + 1) * B])
+        assert np.array_equal(outs[rank][1], e1[rank * B:(rank + 1) * B])
+        assert ulp_diff(outs[rank][2], ef[rank * B:(rank + 1) * B]).max() == 0

@@ -180,6 +180,21 @@ int ofdg_forward(ofdg_ctx* ctx, float* d_image0, float* d_image1, float* d_flow,
 /* Wait for `stream` and report device-side error flags raised by kernels. */
 int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
 
+/* ---- mode 9 (non-rigid deformation) warp fields: replaces WarpFields::CropGenerator
+ * (WF:469-641), which DataGenerator::Start launches for MODE == 9 (DG:1016-1020). ---- */
+/* Generate n_fields big fields (side 3*max(W,H)) on the device from seeded displacer
+ * lists (the reference seeds from std::random_device) and cut them into (W+1)x(H+1)
+ * crops; crops are then served like CropGenerator::get_crop (each 3 times, in order). */
+int ofdg_warp_generate(ofdg_ctx* ctx, int n_fields, uint32_t seed);
+/* Install caller-provided crops instead: n x {flow x, flow y, iflow x, iflow y} planes of
+ * (H+1)*(W+1) floats (host memory). */
+int ofdg_warp_upload(ofdg_ctx* ctx, const float* crops, int n);
+int ofdg_warp_info(const ofdg_ctx* ctx, int* n_crops, int* w, int* h);
+int ofdg_warp_download(ofdg_ctx* ctx, int index, float* crop);
+/* Host only: displacer draws of one big field, n x 9 doubles {type, p0, p1, p2, support
+ * cx, cy, sigma_x, sigma_y, angle} (WF:572-610). Returns n, or -n if cap is too small. */
+int ofdg_host_displacers(int width, int height, uint32_t seed, double* out, int cap);
+
 /* ---- inspection (tests / profiling) ---------------------------------------- */
 /* Rasterise one polygon (n double vertices, already in screen space) with the
  * device rasteriser and return the raw AGG coverage (0..255) as w*h bytes. */

@@ -73,6 +73,7 @@ EXPORTS = [
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
+    "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
 ]
@@ -124,6 +125,11 @@ def lib():
         L.ofdg_debug_tables.argtypes = [vp, vp, vp, vp, vp, i32]
         L.ofdg_set_profiling.argtypes = [vp, i32]
         L.ofdg_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+        L.ofdg_warp_generate.argtypes = [vp, i32, C.c_uint32]
+        L.ofdg_warp_upload.argtypes = [vp, vp, i32]
+        L.ofdg_warp_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.ofdg_warp_download.argtypes = [vp, i32, vp]
+        L.ofdg_host_displacers.argtypes = [i32, i32, C.c_uint32, vp, i32]
         L.ofdg_host_sampler_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
         L.ofdg_host_sampler_next.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
         L.ofdg_host_sampler_destroy.argtypes = [vp]
@@ -232,6 +238,27 @@ class Generator:
     def synchronize(self, stream=0):
         self._check(lib().ofdg_synchronize(self.h, C.c_void_p(stream)))
 
+    # -- mode 9 warp fields --
+    def warp_generate(self, n_fields=1, seed=0):
+        self._check(lib().ofdg_warp_generate(self.h, n_fields, seed))
+
+    def warp_upload(self, crops):
+        import numpy as np
+        a = np.ascontiguousarray(crops, np.float32)
+        assert a.ndim == 4 and a.shape[1:] == (4, self.params.height + 1, self.params.width + 1), a.shape
+        self._check(lib().ofdg_warp_upload(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0]))
+
+    def warp_count(self):
+        n = C.c_int()
+        self._check(lib().ofdg_warp_info(self.h, C.byref(n), None, None))
+        return n.value
+
+    def warp_download(self, index):
+        import numpy as np
+        a = np.zeros((4, self.params.height + 1, self.params.width + 1), np.float32)
+        self._check(lib().ofdg_warp_download(self.h, index, a.ctypes.data_as(C.c_void_p)))
+        return a
+
     # -- inspection --
     def debug_rasterize(self, xy):
         import numpy as np
@@ -329,6 +356,15 @@ def host_realize(params, pool_n, pool_w, pool_h, tasks, n_tasks, bps, n_bps, cap
     if rc != OK:
         raise OfdgError(rc, lib().ofdg_host_last_error().decode())
     return sm[:ns.value].copy(), om[:no.value].copy()
+
+
+def host_displacers(width, height, seed):
+    import numpy as np
+    out = np.zeros((1024, 9), np.float64)
+    n = lib().ofdg_host_displacers(width, height, seed, out.ctypes.data_as(C.c_void_p), 1024)
+    if n < 0:
+        raise OfdgError(ECAPACITY, "displacer capacity")
+    return out[:n].copy()
 
 
 def parse_prototxt(text):

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "ofdg_device.h"
+#include "warpfields.h"
 
 namespace ofdg {
 
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
                                                    const double* __restrict__ cs_tab, int W, int H,
                                                    DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
                                                    int4* __restrict__ obj_box, uint32_t* __restrict__ err,
-                                                   int* __restrict__ item_count) {
+                                                   int* __restrict__ item_count,
+                                                   const DevCropRef* __restrict__ crops) {
   __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
   __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // consumed by bin_kernel (next launch)
@@ -232,8 +234,15 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
       x0 = 1; x1 = 0; y0 = 1; y1 = 0;  // nothing on screen
     } else {
       x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+      int bx0 = x0, by0 = y0, bx1 = x1, by1 = y1;
+      if ((sf & 1) && S.deform > 0) {
+        // mode 9: the frame-1 mask is re-sampled through the inverse warp field, so it can
+        // reach max |iflow| (+ the bilinear footprint) beyond the outline's box
+        const int d = (int)ceilf(__uint_as_float(*crops[S.deform - 1].max_bits)) + 2;
+        bx0 = max(x0 - d, 0); by0 = max(y0 - d, 0); bx1 = min(x1 + d, W - 1); by1 = min(y1 + d, H - 1);
+      }
       int* box = reinterpret_cast<int*>(&obj_box[S.object * 2 + (sf & 1)]);  // union over the object's outlines, per frame
-      atomicMin(box + 0, x0); atomicMin(box + 1, y0); atomicMin(box + 2, -x1); atomicMin(box + 3, -y1);
+      atomicMin(box + 0, bx0); atomicMin(box + 1, by0); atomicMin(box + 2, -bx1); atomicMin(box + 3, -by1);
     }
     f.n_verts = n_verts;
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
@@ -753,15 +762,51 @@ __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__
 // touched tile, zero outside the outlines).
 // Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799,
 // computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
-// At most 4 waves per SIMD: compose is bandwidth-bound well before that, and the spare
-// registers let the (latency-bound) preparation kernels of the next batch co-reside.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose_kernel(RenderDims dm, const DevSample* __restrict__ samples,
-                                                      const DevObject* __restrict__ objects,
-                                                      const unsigned long long* __restrict__ tile_masks,
-                                                      const uint8_t* __restrict__ cov,
-                                                      const uint32_t* __restrict__ pool,
-                                                      float* __restrict__ img0, float* __restrict__ img1,
-                                                      float* __restrict__ flow) {
+// CImg<float>::_linear_atXY (Neumann): clamp, nx = dx > 0 ? x+1 : x, fp32 polynomial.
+__device__ __forceinline__ float linear_neumann(const float* __restrict__ img, int w, int h, float fx, float fy) {
+  const float nfx = fx <= 0 ? 0 : (fx >= (float)(w - 1) ? (float)(w - 1) : fx);
+  const float nfy = fy <= 0 ? 0 : (fy >= (float)(h - 1) ? (float)(h - 1) : fy);
+  const unsigned x = (unsigned)nfx, y = (unsigned)nfy;
+  const float dx = nfx - (float)x, dy = nfy - (float)y;
+  const unsigned nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
+  const float Icc = img[(size_t)y * w + x], Inc = img[(size_t)y * w + nx];
+  const float Icn = img[(size_t)ny * w + x], Inn = img[(size_t)ny * w + nx];
+  return Icc + dx * (Inc - Icc + dy * (Icc + Inn - Icn - Inc)) + dy * (Icn - Icc);
+}
+
+// ---- mode 9 helpers: CImg<unsigned char>::linear_atXY(fx, fy, 0, c, 0) (Dirichlet), fp32 ----
+struct Taps {
+  int x, y;      // integer tap (x, y); the others are x+1 / y+1
+  float dx, dy;  // fractions
+  bool ok;       // false: NaN displacement -> the result is 0 (SURVEY F-9)
+};
+__device__ __forceinline__ Taps make_taps(float fx, float fy) {
+  Taps t;
+  t.ok = (fx == fx) && (fy == fy) && fabsf(fx) < 1e8f && fabsf(fy) < 1e8f;
+  if (!t.ok) { fx = 0.f; fy = 0.f; }
+  t.x = (int)fx - (fx >= 0 ? 0 : 1);
+  t.y = (int)fy - (fy >= 0 ? 0 : 1);
+  t.dx = fx - (float)t.x;
+  t.dy = fy - (float)t.y;
+  return t;
+}
+__device__ __forceinline__ int lerp_u8(const Taps& t, float Icc, float Inc, float Icn, float Inn) {
+  const float v = Icc + t.dx * (Inc - Icc + t.dy * (Icc + Inn - Icn - Inc)) + t.dy * (Icn - Icc);
+  return t.ok ? (int)(unsigned char)v : 0;
+}
+
+// Body of the compose kernel; kDeform adds the mode-9 paths (masks, textures and flow
+// re-sampled through per-object warp crops).
+template <bool kDeform>
+__device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
+                                             const DevObject* __restrict__ objects,
+                                             const unsigned long long* __restrict__ tile_masks,
+                                             const uint8_t* __restrict__ cov,
+                                             const uint32_t* __restrict__ pool,
+                                             float* __restrict__ img0, float* __restrict__ img1,
+                                             float* __restrict__ flow,
+                                             const DevShapeFrame* __restrict__ frames,
+                                             const DevCropRef* __restrict__ crops) {
   // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give
   // every XCD a contiguous run of tiles (whole samples): their background rows,
   // coverage slots and object records then stay in that XCD's L2.
@@ -844,6 +889,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         fu[p] = (float)(ix - (double)save_x);
         fv[p] = (float)(iy - (double)save_y);
       }
+      if constexpr (kDeform) {
+        if (B.deform > 0) {  // background re-sampled through its (2W x 2H, upscaled) warp crop (DG:670-678, 714-717)
+          const DevCropRef C = crops[B.deform - 1];
+          const size_t cn = (size_t)C.w * C.h;
+          const int X0 = x0 + W / 2, Y = y + H / 2;
+#pragma unroll 1
+          for (int p = 0; p < kPx; ++p) {
+            const int X = X0 + p;
+            const float iwx = C.data[2 * cn + (size_t)Y * C.w + X], iwy = C.data[3 * cn + (size_t)Y * C.w + X];
+            const Taps t = make_taps((float)X + iwx, (float)Y + iwy);
+            uint32_t tap[4] = {0, 0, 0, 0};
+            if (t.ok) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int ty = t.y + j;
+                if (ty < 0 || ty >= g.th) continue;
+                const RowDDA Rj = make_row(B.tex_inv, ty, g.tw, g.nshift);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  const int tx = t.x + i;
+                  if (tx >= 0 && tx < g.tw) tap[2 * j + i] = sample_bilinear(tex, g, Rj, tx);
+                }
+              }
+            }
+            uint32_t o = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int sh = 8 * c;
+              o |= (uint32_t)lerp_u8(t, (float)((tap[0] >> sh) & 255u), (float)((tap[1] >> sh) & 255u),
+                                     (float)((tap[2] >> sh) & 255u), (float)((tap[3] >> sh) & 255u)) << sh;
+            }
+            px1[p] = o;
+            // flow: + forward field at the destination (detour coordinates), Neumann
+            double ix = (double)(x0 + p + W / 2) + (double)(-W), iy = by;
+            xform(B.motion, ix, iy);
+            ix = ix + (double)W; iy = iy + (double)H;
+            if (ix >= 0 && ix < (double)(2 * W) && iy >= 0 && iy < (double)(2 * H)) {
+              fu[p] += linear_neumann(C.data, C.w, C.h, (float)ix, (float)iy);
+              fv[p] += linear_neumann(C.data + cn, C.w, C.h, (float)ix, (float)iy);
+            }
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
@@ -869,6 +957,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     int m0[kPx], m1[kPx];   // blending masks for the two frames
     int na0[kPx];           // thresholded frame-0 mask (index image)
+    // mode 9: frame-1 mask bytes (AA and thresholded) of one outline re-sampled through the
+    // inverse field (MovingObjectBase::renderMasks, DG:370-386).  Taps outside the outline's
+    // rasterised box read as 0 (the mask is 0 there; outside the frame: Dirichlet).
+    auto warped_mask1 = [&](int shape, const DevCropRef& C, int p, int& aa, int& na) {
+      aa = 0; na = 0;
+      if (!inside || !has1) return;
+      const DevShapeFrame F = frames[shape * 2 + 1];
+      if (F.x0 > F.x1) return;
+      const size_t cn = (size_t)C.w * C.h;
+      const int x = x0 + p;
+      const float iwx = C.data[2 * cn + (size_t)y * C.w + x], iwy = C.data[3 * cn + (size_t)y * C.w + x];
+      const Taps t = make_taps((float)x + iwx, (float)y + iwy);
+      if (!t.ok || t.x + 1 < F.x0 || t.x > F.x1 || t.y + 1 < F.y0 || t.y > F.y1) return;
+      const uint8_t* c = cov + ((size_t)shape * 2 + 1) * slot_bytes;
+      float va[4], vn[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int tx = t.x + i, ty = t.y + j;
+          int cv = 0;
+          if (tx >= F.x0 && tx <= F.x1 && ty >= F.y0 && ty <= F.y1) cv = c[(size_t)ty * W + tx];
+          va[2 * j + i] = (float)aa_byte(cv);
+          vn[2 * j + i] = cv >= 128 ? 255.f : 0.f;
+        }
+      aa = lerp_u8(t, va[0], va[1], va[2], va[3]);
+      na = lerp_u8(t, vn[0], vn[1], vn[2], vn[3]);
+    };
+
     if (O.kind == 1) {
       const uint32_t c0w = nc0, c1w = nc1;
       prefetch(omask);
@@ -878,6 +995,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         na0[p] = c0 >= 128 ? 255 : 0;
         m0[p] = dm.use_aa ? aa_byte(c0) : na0[p];
         m1[p] = dm.use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0);
+      }
+      if constexpr (kDeform) {
+        if (O.deform > 0) {
+          const DevCropRef C = crops[O.deform - 1];
+#pragma unroll 1
+          for (int p = 0; p < kPx; ++p) {
+            int aa, na;
+            warped_mask1(O.first_shape, C, p, aa, na);
+            m1[p] = dm.use_aa ? aa : na;
+          }
+        }
       }
     } else {
       // composite: sequential fp32 add / subtract over the components (DG:591-646)
@@ -895,8 +1023,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int p = 0; p < kPx; ++p) {
           const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
-          const int va0 = aa_byte(c0), va1 = aa_byte(c1);
-          const int vn0 = c0 >= 128 ? 255 : 0, vn1 = c1 >= 128 ? 255 : 0;
+          const int va0 = aa_byte(c0);
+          int va1 = aa_byte(c1);
+          const int vn0 = c0 >= 128 ? 255 : 0;
+          int vn1 = c1 >= 128 ? 255 : 0;
+          if constexpr (kDeform) {
+            if (O.deform > 0) warped_mask1(O.first_shape + k, crops[O.deform - 1], p, va1, vn1);  // components warp individually
+          }
           if (additive) {
             ua0[p] = comp_add(ua0[p], va0); ua1[p] = comp_add(ua1[p], va1);
             na0[p] = comp_add(na0[p], vn0); un1[p] = comp_add(un1[p], vn1);
@@ -923,10 +1056,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t t1[kPx] = {0, 0, 0, 0};
     if (any0)  // frame 0 texture: identity warp == the crop itself (DG:339-340)
       q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
-    if (any1) {
+    bool deform_tex = false;
+    if constexpr (kDeform) deform_tex = (O.deform > 0);
+    if (any1 && !deform_tex) {
       const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) t1[p] = sample_bilinear(tex, g, R, x0 + p);
+    }
+    if constexpr (kDeform) {
+      if (any1 && deform_tex) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
+        const DevCropRef C = crops[O.deform - 1];
+        const size_t cn = (size_t)C.w * C.h;
+#pragma unroll 1
+        for (int p = 0; p < kPx; ++p) {
+          if (!m1[p]) continue;
+          const int x = x0 + p;
+          const float iwx = C.data[2 * cn + (size_t)y * C.w + x], iwy = C.data[3 * cn + (size_t)y * C.w + x];
+          const Taps t = make_taps((float)x + iwx, (float)y + iwy);
+          uint32_t tap[4] = {0, 0, 0, 0};
+          if (t.ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int ty = t.y + j;
+              if (ty < 0 || ty >= H) continue;
+              const RowDDA Rj = make_row(O.tex_inv, ty, W, g.nshift);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int tx = t.x + i;
+                if (tx >= 0 && tx < W) tap[2 * j + i] = sample_bilinear(tex, g, Rj, tx);
+              }
+            }
+          }
+          uint32_t o = 0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int sh = 8 * c;
+            o |= (uint32_t)lerp_u8(t, (float)((tap[0] >> sh) & 255u), (float)((tap[1] >> sh) & 255u),
+                                   (float)((tap[2] >> sh) & 255u), (float)((tap[3] >> sh) & 255u)) << sh;
+          }
+          t1[p] = o;
+        }
+      }
     }
     if (any0) {
       const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
@@ -947,6 +1117,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           xform(O.motion, ix, iy);
           fu[p] = (float)(ix - (double)save_x);
           fv[p] = (float)(iy - (double)save_y);
+          if constexpr (kDeform) {
+            if (O.deform > 0 && ix >= 0 && ix < (double)W && iy >= 0 && iy < (double)H) {  // DG:403-406
+              const DevCropRef C = crops[O.deform - 1];
+              fu[p] += linear_neumann(C.data, C.w, C.h, (float)ix, (float)iy);
+              fv[p] += linear_neumann(C.data + (size_t)C.w * C.h, C.w, C.h, (float)ix, (float)iy);
+            }
+          }
         }
       }
     }
@@ -970,6 +1147,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
   __builtin_nontemporal_store(u, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o));
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
+}
+
+// At most 4 waves per SIMD: compose is bandwidth-bound well before that, and the spare
+// registers let the (latency-bound) preparation kernels of the next batch co-reside.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ tile_masks, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow) {
+  compose_body<false>(dm, samples, objects, tile_masks, cov, pool, img0, img1, flow, nullptr, nullptr);
+}
+// Mode 9: the same kernel with the deformation paths compiled in.
+__global__ __launch_bounds__(256) void compose_deform_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ tile_masks, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops) {
+  compose_body<true>(dm, samples, objects, tile_masks, cov, pool, img0, img1, flow, frames, crops);
+}
+
+// --------------------------------------------------------------------------
+// Mode-9 warp fields (reference: src/caffe/WarpFields.cpp = WF).
+// A field is 4 planes of S*S floats: flow x, flow y, iflow x, iflow y.
+// --------------------------------------------------------------------------
+// DisplacementComposer::flow_at / iflow_at sampled on the S x S grid (WF:296-316, 347-354)
+__global__ __launch_bounds__(256) void wf_sample_kernel(const DevDisplacer* __restrict__ disp, int n_disp, int S,
+                                                        float* __restrict__ field) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * S) return;
+  const float x = (float)(i % S), y = (float)(i / S);
+  float fu = 0, fv = 0, iu = 0, iv = 0;
+  for (int k = 0; k < n_disp; ++k) {
+    const DevDisplacer& D = disp[k];
+    float u, v, ju, jv;
+    if (D.type == 0) {
+      u = D.dx; v = D.dy; ju = -D.dx; jv = -D.dy;
+    } else {
+      const float dx = x - D.cx, dy = y - D.cy;
+      if (D.type == 1) {
+        u = (D.cos_nomega * dx - D.sin_nomega * dy) - dx;
+        v = (D.sin_nomega * dx + D.cos_nomega * dy) - dy;
+        ju = (D.cos_omega * dx - D.sin_omega * dy) - dx;
+        jv = (D.sin_omega * dx + D.cos_omega * dy) - dy;
+      } else {
+        u = D.factor * dx - dx; v = D.factor * dy - dy;
+        ju = D.ifactor * dx - dx; jv = D.ifactor * dy - dy;
+      }
+    }
+    // Gaussian2D::at (WF:101-112)
+    const float rx = D.a * (x - D.scx) + D.b * (y - D.scy);
+    const float ry = (D.c * (x - D.scx) + D.d * (y - D.scy)) * D.ratio_x_y;
+    const float dist_sq = rx * rx + ry * ry;
+    const float w = D.normalizer * (D.gauss_prefactor * expf(-dist_sq / D.two_sigma_sq));
+    fu += u * w; fv += v * w;
+    iu += ju * w; iv += jv * w;
+  }
+  const size_t n = (size_t)S * S;
+  field[i] = fu; field[n + i] = fv; field[2 * n + i] = iu; field[3 * n + i] = iv;
+}
+
+// One self-composition pass f <- f + f o (id + f) for both the forward pair (planes 0,1)
+// and the inverse pair (planes 2,3) (WF:366-384, 406-424); flags pixels leaving the field.
+__global__ __launch_bounds__(256) void wf_compose_kernel(const float* __restrict__ from, float* __restrict__ to, int S,
+                                                         uint8_t* __restrict__ flagged) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pair = blockIdx.y;  // 0 forward, 1 inverse
+  if (i >= S * S) return;
+  const size_t n = (size_t)S * S;
+  const float* fx_p = from + (size_t)(2 * pair) * n;
+  const float* fy_p = fx_p + n;
+  const int x = i % S, y = i / S;
+  const float fx = fx_p[i], fy = fy_p[i];
+  float ox = fx, oy = fy;
+  if ((float)x + fx < 0 || (float)x + fx >= (float)S || (float)y + fy < 0 || (float)y + fy >= (float)S) {
+    flagged[(size_t)pair * n + i] = 255;
+  } else {
+    ox = fx + linear_neumann(fx_p, S, S, (float)x + fx, (float)y + fy);
+    oy = fy + linear_neumann(fy_p, S, S, (float)x + fx, (float)y + fy);
+  }
+  to[(size_t)(2 * pair) * n + i] = ox;
+  to[(size_t)(2 * pair + 1) * n + i] = oy;
+}
+
+// NaN-out flagged pixels, then clamp_near_zeros (WF:389-398, 425-434, 444-455)
+__global__ __launch_bounds__(256) void wf_finish_kernel(float* __restrict__ field, int S, const uint8_t* __restrict__ flagged) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pair = blockIdx.y;
+  if (i >= S * S) return;
+  const size_t n = (size_t)S * S;
+  float* fx_p = field + (size_t)(2 * pair) * n;
+  float* fy_p = fx_p + n;
+  const int x = i % S, y = i / S;
+  float fx = fx_p[i], fy = fy_p[i];
+  bool flag = flagged[(size_t)pair * n + i] != 0;
+  if ((float)x + fx < 0 || (float)x + fx >= (float)S || (float)y + fy < 0 || (float)y + fy >= (float)S) flag = true;
+  if (flag) {
+    fx = __int_as_float(0x7fc00000); fy = fx;
+  } else {
+    if (fabsf(fx) < 1e-3f) fx = 0.f;
+    if (fabsf(fy) < 1e-3f) fy = 0.f;
+  }
+  fx_p[i] = fx; fy_p[i] = fy;
+}
+
+// get_crop(x, y, x+W, y+H) (WF:623-624): copy the four planes of one crop out of a field,
+// and reduce max |iflow| (NaNs ignored) for the box dilation of deforming objects.
+__global__ __launch_bounds__(256) void wf_crop_kernel(const float* __restrict__ field, int S, int x0, int y0, int cw, int ch,
+                                                      float* __restrict__ crop, unsigned* __restrict__ max_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  if (i < cw * ch) {
+    const int x = i % cw, y = i / cw;
+    const size_t n = (size_t)S * S, cn = (size_t)cw * ch;
+    for (int f = 0; f < 4; ++f) {
+      const float v = field[f * n + (size_t)(y0 + y) * S + (x0 + x)];
+      crop[f * cn + i] = v;
+      if (f >= 2 && v == v) m = fmaxf(m, fabsf(v));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(max_bits, __float_as_uint(m));  // non-negative floats order as uints
+}
+
+// Background warp field: CImg resize(2W, 2H, -100, -100, 3) then *= 2 (DG:1197-1200), linear
+// interpolation, X pass then Y pass, each pass rounded to float (CImg 2.x linear resize,
+// boundary 0, upscaling branch).  off/foff tables come from the host.
+__global__ __launch_bounds__(256) void wf_resize2_kernel(const float* __restrict__ crop, int cw, int ch, int sx, int sy,
+                                                         const int* __restrict__ xi, const double* __restrict__ xa,
+                                                         const int* __restrict__ yi, const double* __restrict__ ya,
+                                                         float* __restrict__ out, unsigned* __restrict__ max_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  if (i < sx * sy) {
+    const int x = i % sx, y = i / sx;
+    const size_t cn = (size_t)cw * ch, on = (size_t)sx * sy;
+    const int x1 = xi[x], x2 = min(x1 + 1, cw - 1);
+    const int y1 = yi[y], y2 = min(y1 + 1, ch - 1);
+    const double ax = xa[x], ay = ya[y];
+    for (int f = 0; f < 4; ++f) {
+      const float* p = crop + f * cn;
+      const float r1 = (float)((1 - ax) * (double)p[(size_t)y1 * cw + x1] + ax * (double)p[(size_t)y1 * cw + x2]);
+      const float r2 = (float)((1 - ax) * (double)p[(size_t)y2 * cw + x1] + ax * (double)p[(size_t)y2 * cw + x2]);
+      const float v = (float)((1 - ay) * (double)r1 + ay * (double)r2);
+      const float v2 = (float)((double)v * 2.);
+      out[f * on + i] = v2;
+      if (f >= 2 && v2 == v2) m = fmaxf(m, fabsf(v2));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(max_bits, __float_as_uint(m));
 }
 
 // --------------------------------------------------------------------------

@@ -239,6 +239,9 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt) : cf
   if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_last_error(nullptr));
   try {
     load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+    // DataGenerator::Start launches the CropGenerator for MODE == 9 (DataGenerator.cpp:1016-1020)
+    if (cfg_.params.mode == 9 && ofdg_warp_generate(ctx_, 2, (uint32_t)cfg_.params.seed) != OFDG_OK)
+      throw std::runtime_error(std::string("warp field generation: ") + ofdg_last_error(ctx_));
   } catch (...) {
     ofdg_destroy(ctx_);
     ctx_ = nullptr;

@@ -18,6 +18,7 @@
 #include "ofdg_device.h"
 #include "realize.h"
 #include "sampler_ref.h"
+#include "warpfields.h"
 
 using namespace ofdg;
 
@@ -63,6 +64,9 @@ struct ofdg_ctx {
     int res_objects = 0;
     hipEvent_t ev_uploaded = nullptr;
     bool upload_pending = false;
+    DevBuf<DevCropRef> d_croptab;      // mode 9: crops of this batch's deforming objects
+    DevBuf<float> d_bgwarp;            // mode 9: upscaled (2W x 2H) background crops
+    DevBuf<unsigned> d_bgwarp_max;
     hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records
     bool compose_pending = false;
     int* d_item_count = nullptr;
@@ -74,6 +78,13 @@ struct ofdg_ctx {
   size_t h_stage_bytes = 0;
   hipEvent_t stage_free = nullptr;
   bool stage_pending = false;
+  // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
+  float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
+  unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
+  CropServer crop_server;
+  int rs_w = 0, rs_h = 0;          // CImg resize tables for the background crops
+  int *d_rs_xi = nullptr, *d_rs_yi = nullptr;
+  double *d_rs_xa = nullptr, *d_rs_ya = nullptr;
   // Coverage workspaces: two, used alternately, so that the preparation kernels of
   // launch i+1 (internal stream) overlap the compose kernel of launch i (caller's stream).
   DevBuf<uint8_t> d_cov2[2];
@@ -191,6 +202,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_tile_masks.release(); sl.d_items.release(); sl.d_obj_box.release();
+    sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
   for (int i = 0; i < 2; ++i) {
@@ -203,6 +215,9 @@ void ofdg_destroy(ofdg_ctx* c) {
     if (sl.ev_composed) (void)hipEventDestroy(sl.ev_composed);
   }
   if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+  if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
+  if (c->d_warp) (void)hipFree(c->d_warp);
+  if (c->d_warp_max) (void)hipFree(c->d_warp_max);
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
@@ -332,7 +347,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
   // geom: outlines + bounding boxes (also zeroes the raster item counter)
   hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(256), 0, ps, sl.d_shapes.p,
-                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, sl.d_obj_box.p, c->d_err, sl.d_item_count);
+                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, sl.d_obj_box.p, c->d_err, sl.d_item_count, sl.d_croptab.p);
   HIP_OK(c, hipGetLastError());
   // bin: block -> object masks, raster work list
   {
@@ -354,8 +369,13 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
   }
   if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
-                     sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow);
+  if (c->prm.mode == 9)
+    hipLaunchKernelGGL(compose_deform_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm,
+                       sl.d_samples.p, sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow,
+                       sl.d_frames.p, sl.d_croptab.p);
+  else
+    hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
+                       sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow);
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
   if (c->overlap) {
@@ -376,7 +396,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   // the previous call's host->device copies must have left the staging buffer
   if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
   sl.res_samples = 0;
-  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &sl.batch, &c->err);
+  int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &sl.batch, &c->err, &c->crop_server);
   if (rc != OFDG_OK) return rc;
   const RealizedBatch& B = sl.batch;
   const size_t n_shapes = B.shapes.size(), n_obj = B.objects.size();
@@ -421,6 +441,66 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   if (b_shapes) HIP_OK(c, hipMemcpyAsync(sl.d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipMemcpyAsync(sl.d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipMemcpyAsync(sl.d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
+  if (!B.crops.empty()) {  // mode 9: this batch's crop table (+ upscaled background copies)
+    const int W = c->prm.width, H = c->prm.height;
+    const size_t crop_floats = (size_t)4 * (W + 1) * (H + 1), bg_floats = (size_t)4 * 2 * W * 2 * H;
+    size_t n_bg = 0;
+    for (const CropUse& u : B.crops) n_bg += u.background ? 1 : 0;
+    HIP_OK(c, sl.d_croptab.reserve(B.crops.size()));
+    if (n_bg) {
+      HIP_OK(c, sl.d_bgwarp.reserve(n_bg * bg_floats));
+      HIP_OK(c, sl.d_bgwarp_max.reserve(n_bg));
+      HIP_OK(c, hipMemsetAsync(sl.d_bgwarp_max.p, 0, n_bg * sizeof(unsigned), st));
+      // CImg linear resize tables (X then Y), boundary 0, upscaling branch
+      if (c->rs_w != W || c->rs_h != H) {
+        auto table = [](int w, int sx, std::vector<int>& idx, std::vector<double>& alpha) {
+          idx.resize(sx); alpha.resize(sx);
+          const double f = (sx > w) ? (sx > 1 ? (w - 1.) / (sx - 1) : 0) : (double)w / sx;
+          double curr = 0, old = 0;
+          int at = 0;
+          for (int x = 0; x < sx; ++x) {
+            alpha[x] = curr - (unsigned int)curr;
+            idx[x] = at;
+            old = curr;
+            curr = std::min(w - 1., curr + f);
+            at += (int)((unsigned int)curr - (unsigned int)old);
+          }
+        };
+        std::vector<int> xi, yi;
+        std::vector<double> xa, ya;
+        table(W + 1, 2 * W, xi, xa);
+        table(H + 1, 2 * H, yi, ya);
+        if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
+        HIP_OK(c, hipMalloc((void**)&c->d_rs_xi, xi.size() * sizeof(int)));
+        HIP_OK(c, hipMalloc((void**)&c->d_rs_xa, xa.size() * sizeof(double)));
+        HIP_OK(c, hipMalloc((void**)&c->d_rs_yi, yi.size() * sizeof(int)));
+        HIP_OK(c, hipMalloc((void**)&c->d_rs_ya, ya.size() * sizeof(double)));
+        HIP_OK(c, hipMemcpy(c->d_rs_xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(c, hipMemcpy(c->d_rs_xa, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_OK(c, hipMemcpy(c->d_rs_yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(c, hipMemcpy(c->d_rs_ya, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->rs_w = W; c->rs_h = H;
+      }
+    }
+    std::vector<DevCropRef> tab(B.crops.size());
+    size_t bg_at = 0;
+    for (size_t k = 0; k < B.crops.size(); ++k) {
+      const float* src = c->d_warp + (size_t)B.crops[k].crop * crop_floats;
+      if (B.crops[k].background) {
+        float* dst = sl.d_bgwarp.p + bg_at * bg_floats;
+        hipLaunchKernelGGL(wf_resize2_kernel, dim3((2 * W * 2 * H + 255) / 256), dim3(256), 0, st, src, W + 1, H + 1, 2 * W, 2 * H,
+                           c->d_rs_xi, c->d_rs_xa, c->d_rs_yi, c->d_rs_ya, dst, sl.d_bgwarp_max.p + bg_at);
+        HIP_OK(c, hipGetLastError());
+        tab[k] = DevCropRef{dst, sl.d_bgwarp_max.p + bg_at, 2 * W, 2 * H};
+        ++bg_at;
+      } else {
+        tab[k] = DevCropRef{src, c->d_warp_max + B.crops[k].crop, W + 1, H + 1};
+      }
+    }
+    // small table: a synchronous copy from pageable memory is fine here (upload path)
+    HIP_OK(c, hipMemcpyAsync(sl.d_croptab.p, tab.data(), tab.size() * sizeof(DevCropRef), hipMemcpyHostToDevice, st));
+    HIP_OK(c, hipStreamSynchronize(st));  // `tab` is a stack vector
+  }
   HIP_OK(c, hipEventRecord(c->stage_free, st));
   c->stage_pending = true;
   if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
@@ -494,6 +574,111 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
     return OFDG_ECAPACITY;
   }
   return OFDG_OK;
+}
+
+// ---- mode 9 warp fields -----------------------------------------------------------------------------
+static int warp_alloc(ofdg_ctx* c, int n_crops) {
+  const size_t crop_floats = (size_t)4 * (c->prm.width + 1) * (c->prm.height + 1);
+  HIP_OK(c, hipDeviceSynchronize());
+  if (c->d_warp) { HIP_OK(c, hipFree(c->d_warp)); c->d_warp = nullptr; }
+  if (c->d_warp_max) { HIP_OK(c, hipFree(c->d_warp_max)); c->d_warp_max = nullptr; }
+  HIP_OK(c, hipMalloc((void**)&c->d_warp, (size_t)n_crops * crop_floats * sizeof(float)));
+  HIP_OK(c, hipMalloc((void**)&c->d_warp_max, (size_t)n_crops * sizeof(unsigned)));
+  HIP_OK(c, hipMemset(c->d_warp_max, 0, (size_t)n_crops * sizeof(unsigned)));
+  c->crop_server = CropServer();
+  c->crop_server.n_crops = n_crops;
+  return OFDG_OK;
+}
+
+// Replaces WarpFields::CropGenerator (WF:469-641): n_fields big fields of side 3*max(W,H)
+// are generated on the device from seeded displacer lists (seed, seed+1, ...), composed
+// 17 times with themselves (x 2^17), cleaned, and cut into (W+1) x (H+1) crops.
+int ofdg_warp_generate(ofdg_ctx* c, int n_fields, uint32_t seed) {
+  if (!c || n_fields < 1) return OFDG_EINVAL;
+  const int W = c->prm.width, H = c->prm.height;
+  const int S = std::max(W, H) * 3;
+  std::vector<std::pair<int, int>> org;  // crop grid (WF:617-633)
+  for (int y = H / 4; y < S - 5 * H / 4; y += H / 3)
+    for (int x = W / 4; x < S - 5 * W / 4; x += W / 3) org.push_back({x, y});
+  if (org.empty()) { c->err = "frame too small for warp crops"; return OFDG_EINVAL; }
+  int rc = warp_alloc(c, n_fields * (int)org.size());
+  if (rc != OFDG_OK) return rc;
+  const size_t n = (size_t)S * S;
+  float *fa = nullptr, *fb = nullptr;
+  uint8_t* flagged = nullptr;
+  DevDisplacer* dd = nullptr;
+  HIP_OK(c, hipMalloc((void**)&fa, 4 * n * sizeof(float)));
+  HIP_OK(c, hipMalloc((void**)&fb, 4 * n * sizeof(float)));
+  HIP_OK(c, hipMalloc((void**)&flagged, 2 * n));
+  const int cw = W + 1, ch = H + 1;
+  const size_t crop_floats = (size_t)4 * cw * ch;
+  const int blocks = (int)((n + 255) / 256);
+  for (int f = 0; f < n_fields; ++f) {
+    std::vector<DevDisplacer> disp = make_device_displacers(make_displacer_params(W, H, seed + (uint32_t)f));
+    if (dd) { HIP_OK(c, hipFree(dd)); dd = nullptr; }
+    HIP_OK(c, hipMalloc((void**)&dd, std::max<size_t>(1, disp.size()) * sizeof(DevDisplacer)));
+    HIP_OK(c, hipMemcpy(dd, disp.data(), disp.size() * sizeof(DevDisplacer), hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemset(flagged, 0, 2 * n));
+    hipLaunchKernelGGL(wf_sample_kernel, dim3(blocks), dim3(256), 0, 0, dd, (int)disp.size(), S, fa);
+    float *from = fa, *to = fb;
+    for (int iter = 17; iter > 0; --iter) {  // WF:366, 406
+      hipLaunchKernelGGL(wf_compose_kernel, dim3(blocks, 2), dim3(256), 0, 0, from, to, S, flagged);
+      std::swap(from, to);
+    }
+    hipLaunchKernelGGL(wf_finish_kernel, dim3(blocks, 2), dim3(256), 0, 0, from, S, flagged);
+    for (size_t k = 0; k < org.size(); ++k) {
+      const size_t ci = (size_t)f * org.size() + k;
+      hipLaunchKernelGGL(wf_crop_kernel, dim3((cw * ch + 255) / 256), dim3(256), 0, 0, from, S, org[k].first, org[k].second, cw, ch,
+                         c->d_warp + ci * crop_floats, c->d_warp_max + ci);
+    }
+    HIP_OK(c, hipGetLastError());
+    HIP_OK(c, hipDeviceSynchronize());
+  }
+  HIP_OK(c, hipFree(fa)); HIP_OK(c, hipFree(fb)); HIP_OK(c, hipFree(flagged));
+  if (dd) HIP_OK(c, hipFree(dd));
+  return OFDG_OK;
+}
+
+// Install caller-provided crops: n x 4 planes (flow x, flow y, iflow x, iflow y) of (H+1)*(W+1) floats.
+int ofdg_warp_upload(ofdg_ctx* c, const float* crops, int n) {
+  if (!c || !crops || n < 1) return OFDG_EINVAL;
+  int rc = warp_alloc(c, n);
+  if (rc != OFDG_OK) return rc;
+  const size_t plane = (size_t)(c->prm.width + 1) * (c->prm.height + 1), crop_floats = 4 * plane;
+  HIP_OK(c, hipMemcpy(c->d_warp, crops, (size_t)n * crop_floats * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<unsigned> mx(n, 0u);
+  for (int k = 0; k < n; ++k) {
+    float m = 0.f;
+    const float* p = crops + (size_t)k * crop_floats + 2 * plane;
+    for (size_t i = 0; i < 2 * plane; ++i) if (p[i] == p[i]) m = std::max(m, std::fabs(p[i]));
+    std::memcpy(&mx[k], &m, sizeof(float));
+  }
+  HIP_OK(c, hipMemcpy(c->d_warp_max, mx.data(), (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice));
+  return OFDG_OK;
+}
+
+int ofdg_warp_info(const ofdg_ctx* c, int* n_crops, int* w, int* h) {
+  if (!c) return OFDG_EINVAL;
+  if (n_crops) *n_crops = c->crop_server.n_crops;
+  if (w) *w = c->prm.width + 1;
+  if (h) *h = c->prm.height + 1;
+  return OFDG_OK;
+}
+
+int ofdg_warp_download(ofdg_ctx* c, int index, float* crop) {
+  if (!c || !crop || index < 0 || index >= c->crop_server.n_crops) return OFDG_EINVAL;
+  const size_t crop_floats = (size_t)4 * (c->prm.width + 1) * (c->prm.height + 1);
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, hipMemcpy(crop, c->d_warp + (size_t)index * crop_floats, crop_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return OFDG_OK;
+}
+
+// Displacer draws of one big field (host only): n x 9 doubles {type, p0, p1, p2, support cx, cy, sx, sy, angle}.
+int ofdg_host_displacers(int width, int height, uint32_t seed, double* out, int cap) {
+  std::vector<DisplacerParams> d = make_displacer_params(width, height, seed);
+  if ((int)d.size() > cap || !out) return -(int)d.size();
+  std::memcpy(out, d.data(), d.size() * sizeof(DisplacerParams));
+  return (int)d.size();
 }
 
 // ---- inspection ---------------------------------------------------------------------------------

@@ -70,6 +70,13 @@ struct DevSample {
   int32_t n_shapes;
 };
 
+// One served warp crop as the kernels see it (mode 9).
+struct DevCropRef {
+  const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
+  const unsigned* max_bits;  // float bits of max |iflow| over the crop (NaNs ignored)
+  int32_t w, h;
+};
+
 struct RenderDims {
   int32_t W, H;            // output size
   int32_t pool_w, pool_h;  // pool image size (texels are BGRX u32)

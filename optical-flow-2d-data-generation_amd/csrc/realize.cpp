@@ -24,7 +24,7 @@ Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H
   return r;
 }
 
-int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object,
+int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object, int deform,
                std::vector<DevShape>* shapes, std::string* msg) {
   if (p.obj_type != OFDG_OBJ_ELLIPSE && p.obj_type != OFDG_OBJ_POLYGON) {
     *msg = "(RealizeObjectBlueprint) Bad object type, or not intended in this mode";  // DataGenerator.cpp:1143
@@ -39,6 +39,7 @@ int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_
   s.ry = p.ellipse_scale_y;
   s.sample = sample;
   s.object = object;
+  s.deform = deform;
   if (p.obj_type == OFDG_OBJ_POLYGON) {
     if (p.n_segments < 1 || p.n_segments > kMaxSegments) {
       *msg = "polygon blueprint with a segment count outside [1, 20]";
@@ -67,10 +68,23 @@ int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_
 }  // namespace
 
 int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
-                  int n_bps, RealizedBatch* out, std::string* msg) {
+                  int n_bps, RealizedBatch* out, std::string* msg, CropServer* crops) {
   out->shapes.clear();
   out->objects.clear();
   out->samples.clear();
+  out->crops.clear();
+  const bool mode9 = (cfg.mode == 9);
+  auto serve = [&](bool background) -> int {  // returns deform = table index + 1
+    out->crops.push_back(CropUse{crops->get(), background ? 1 : 0});
+    return (int)out->crops.size();
+  };
+  if (mode9 && (!crops || crops->n_crops <= 0)) {
+    for (int t = 0; t < n_tasks; ++t) {
+      bool need = bps[tasks[t].background].do_warpfield_deformation != 0;
+      for (int i = 0; i < tasks[t].n_objects && !need; ++i) need = bps[tasks[t].first_object + i].do_warpfield_deformation != 0;
+      if (need) { *msg = "mode 9 needs warp fields: call ofdg_warp_generate or ofdg_warp_upload first"; return OFDG_EINVAL; }
+    }
+  }
   const int W = cfg.W, H = cfg.H;
   // fg: Texture::getRandomizedCrop() with defaults == exact centre W x H crop
   // (DataGenerator.cpp:87-109 via :1149-1150); bg: 2W x 2H centre crop (parity boundary:
@@ -112,6 +126,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;
       o.first_shape = 0;
       o.n_shapes = 0;
+      if (mode9 && pb.do_warpfield_deformation) o.deform = serve(true);  // DataGenerator.cpp:1194-1202
       out->objects.push_back(o);
     }
     // foreground objects; std::map order == ascending obj_id (DataGenerator.cpp:1216-1223)
@@ -140,16 +155,20 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         }
         o.kind = 2;
         o.n_shapes = p.n_components;
+        // the composite takes its crop before its components, which copy it (DataGenerator.cpp:1120-1128, 1158-1163)
+        if (mode9 && p.do_warpfield_deformation) o.deform = serve(false);
         for (int k = 0; k < p.n_components; ++k) {
           const ofdg_blueprint& c = bps[p.first_component + k];
-          int rc = push_shape(cfg, c, bg_motion, t, (int)out->objects.size(), &out->shapes, msg);
+          const int cdef = (mode9 && c.do_warpfield_deformation) ? o.deform : 0;
+          int rc = push_shape(cfg, c, bg_motion, t, (int)out->objects.size(), cdef, &out->shapes, msg);
           if (rc != OFDG_OK) return rc;
           if (c.is_additive_component) o.additive |= (1u << k);
         }
       } else {
         o.kind = 1;
         o.n_shapes = 1;
-        int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), &out->shapes, msg);
+        if (mode9 && p.do_warpfield_deformation) o.deform = serve(false);  // DataGenerator.cpp:1164-1168
+        int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), o.deform, &out->shapes, msg);
         if (rc != OFDG_OK) return rc;
       }
       out->objects.push_back(o);

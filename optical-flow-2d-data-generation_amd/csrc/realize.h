@@ -44,10 +44,28 @@ inline Mat mat_invert(const Mat& a) {
   return r;
 }
 
+// A warp-crop use of the batch (mode 9): entry k of the batch's crop table.
+struct CropUse {
+  int32_t crop;        // index of the served crop
+  int32_t background;  // 1: the 2W x 2H upscaled copy is needed (DataGenerator.cpp:1194-1202)
+};
+
 struct RealizedBatch {
   std::vector<DevShape> shapes;
   std::vector<DevObject> objects;
   std::vector<DevSample> samples;
+  std::vector<CropUse> crops;  // DevObject/DevShape.deform - 1 indexes this table
+};
+
+// CropGenerator::get_crop (WarpFields.cpp:516-538): crops are served in order, each
+// reuse_same + 1 = 3 times (DataGenerator.cpp:1018); the set is cycled when exhausted.
+struct CropServer {
+  int n_crops = 0, head = 0, counter = 0, reuse_same = 2;
+  int get() {
+    const int c = head % n_crops;
+    if (++counter > reuse_same) { ++head; counter = 0; }
+    return c;
+  }
 };
 
 struct RealizeConfig {
@@ -57,6 +75,6 @@ struct RealizeConfig {
 
 // Returns OFDG_OK or an error code; *msg explains failures.
 int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
-                  int n_bps, RealizedBatch* out, std::string* msg);
+                  int n_bps, RealizedBatch* out, std::string* msg, CropServer* crops = nullptr);
 
 }  // namespace ofdg

@@ -450,6 +450,35 @@ int ofdg_oracle_flowfield(int size, const double* displacers, int n, int iters, 
   return 0;
 }
 
+// Displacer list of one big field for (W, H, seed): n x 9 doubles (DisplacerSpec); returns n.
+int ofdg_oracle_displacers(int W, int H, unsigned seed, double* out, int cap) {
+  std::vector<DisplacerSpec> d = make_displacers(W, H, seed);
+  if ((int)d.size() > cap) return -(int)d.size();
+  for (size_t i = 0; i < d.size(); ++i) std::memcpy(out + 9 * i, &d[i], sizeof(double) * 9);
+  return (int)d.size();
+}
+// One seeded big field -> all its (W+1)x(H+1) crops in the reference's order.
+// crops: n x {flow x, flow y, iflow x, iflow y} planes of (H+1)*(W+1) floats. Returns n (or -needed).
+int ofdg_oracle_warp_crops(int W, int H, unsigned seed, int iters, float* crops, int cap) {
+  const int big = std::max(W, H) * 3;
+  std::vector<std::pair<int, int>> org = crop_origins(W, H);
+  if ((int)org.size() > cap) return -(int)org.size();
+  FlowField ff;
+  ff.init_from_displacers(big, big, make_displacers(W, H, seed), iters);
+  ff.clamp_near_zeros();
+  const int cw = W + 1, ch = H + 1;
+  const size_t plane = (size_t)cw * ch, bplane = (size_t)big * big;
+  for (size_t k = 0; k < org.size(); ++k) {
+    float* dst = crops + k * 4 * plane;
+    for (int f = 0; f < 4; ++f) {
+      const float* src = (f < 2 ? ff.flow.data() : ff.iflow.data()) + (f & 1) * bplane;
+      for (int y = 0; y < ch; ++y)  // get_crop(x, y, x+W, y+H): inclusive
+        std::memcpy(dst + f * plane + (size_t)y * cw, src + (size_t)(org[k].second + y) * big + org[k].first, sizeof(float) * cw);
+    }
+  }
+  return (int)org.size();
+}
+
 // ---- the hot path ---------------------------------------------------------------------
 // flags: bit0 = faithful cost (unused yet: always the reference's per-object structure)
 // warp_crops: for mode 9, n_crops crops of (W+1)x(H+1) {flow[2], iflow[2]} served in

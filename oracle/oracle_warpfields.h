@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <random>
 #include <vector>
 
 namespace oracle {
@@ -277,5 +278,63 @@ struct FlowField {
     for (float& v : iflow) if (std::abs(v) < threshold) v = 0.f;
   }
 };
+
+
+// CropGenerator::worker_thread_loop (WF:540-641) for ONE big field, with the reference's
+// std::random_device seed replaced by `seed` (the reference is not reproducible here,
+// SURVEY F-8).  Returns the displacer list in placement order.
+inline std::vector<DisplacerSpec> make_displacers(int W, int H, unsigned seed) {
+  std::mt19937 mersenne(seed);
+  std::uniform_int_distribution<> displacer_type(0, 2);
+  std::uniform_real_distribution<> generic_param(-1, 1);
+  const int big_size{std::max(W, H) * 3};
+  std::vector<DisplacerSpec> out;
+  const int spacing{200};
+  const int isosceles_spacing{(int)(spacing / 2. * std::sqrt(3.))};
+  const int rows{(big_size + isosceles_spacing - 1) / isosceles_spacing};
+  const int cols{(big_size) / spacing};
+  for (int yidx = 0; yidx < rows; ++yidx) {
+    for (int xidx = 0; xidx < cols; ++xidx) {
+      const int x = xidx * spacing + (yidx % 2 == 1 ? spacing / 2 : 0) + spacing / 2;
+      const int y = yidx * isosceles_spacing + spacing / 2;
+      DisplacerSpec d;
+      d.type = displacer_type(mersenne);
+      // argument evaluation order of the reference's constructor calls: GCC evaluates
+      // function arguments right to left, so the LAST parameter draws first.
+      if (d.type == 0) {
+        const double b = generic_param(mersenne) * 3e-4;
+        const double a = generic_param(mersenne) * 3e-4;
+        d.p0 = a; d.p1 = b; d.p2 = 0;
+      } else if (d.type == 1) {
+        const double c = generic_param(mersenne) * M_PI * 2e-6;
+        const double b = y + generic_param(mersenne) * 10;
+        const double a = x + generic_param(mersenne) * 10;
+        d.p0 = a; d.p1 = b; d.p2 = c;
+      } else {
+        const double c = 1 + generic_param(mersenne) * 2e-6;
+        const double b = y + generic_param(mersenne) * 10;
+        const double a = x + generic_param(mersenne) * 10;
+        d.p0 = a; d.p1 = b; d.p2 = c;
+      }
+      const double s4 = generic_param(mersenne) * M_PI;
+      const double s3 = 50 + generic_param(mersenne) * 20;
+      const double s2 = 50 + generic_param(mersenne) * 20;
+      const double s1 = y + generic_param(mersenne) * 10;
+      const double s0 = x + generic_param(mersenne) * 10;
+      d.sup_cx = s0; d.sup_cy = s1; d.sup_sx = s2; d.sup_sy = s3; d.sup_angle = s4;
+      out.push_back(d);
+    }
+  }
+  return out;
+}
+
+// crop origins of one big field (WF:617-633): y outer, x inner.
+inline std::vector<std::pair<int, int>> crop_origins(int W, int H) {
+  const int big_size{std::max(W, H) * 3};
+  std::vector<std::pair<int, int>> o;
+  for (int y = H / 4; y < big_size - 5 * H / 4; y += H / 3)
+    for (int x = W / 4; x < big_size - 5 * W / 4; x += W / 3) o.push_back({x, y});
+  return o;
+}
 
 }  // namespace oracle

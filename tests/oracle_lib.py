@@ -88,6 +88,8 @@ def lib():
         L.ofdg_oracle_draw_image_value.restype = C.c_uint8
         L.ofdg_oracle_draw_image_value.argtypes = [C.c_uint8] * 3
         L.ofdg_oracle_flowfield.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ofdg_oracle_displacers.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_int]
+        L.ofdg_oracle_warp_crops.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_int]
         L.ofdg_oracle_render.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int, C.c_int,
@@ -185,6 +187,21 @@ def flowfield(size, displacers, iters=17):
     iflow = np.zeros((2, size, size), np.float32)
     lib().ofdg_oracle_flowfield(size, _ptr(d), len(d), iters, _ptr(flow), _ptr(iflow))
     return flow, iflow
+
+
+def displacers(W, H, seed):
+    out = np.zeros((1024, 9), np.float64)
+    n = lib().ofdg_oracle_displacers(W, H, seed, _ptr(out), 1024)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def warp_crops(W, H, seed, iters=17, cap=64):
+    """All crops of one seeded big field: float32 [n, 4, H+1, W+1] (flow x, y, iflow x, y)."""
+    out = np.zeros((cap, 4, H + 1, W + 1), np.float32)
+    n = lib().ofdg_oracle_warp_crops(W, H, seed, iters, _ptr(out), cap)
+    assert n >= 0, -n
+    return out[:n].copy()
 
 
 def render(params, tasks, n_tasks, bps, n_bps, pool, warp_crops=None, reuse=2, n_threads=1):

@@ -326,3 +326,78 @@ def test_forward_shards_across_ranks(ofdg, oracle):
         assert np.array_equal(outs[rank][0], e0[rank * B:(rank + 1) * B])
         assert np.array_equal(outs[rank][1], e1[rank * B:(rank + 1) * B])
         assert ulp_diff(outs[rank][2], ef[rank * B:(rank + 1) * B]).max() == 0
+
+
+def nan_equal_ulp(a, b):
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), "NaN patterns differ"
+    d = ulp_diff(np.where(na, 0, a), np.where(nb, 0, b))
+    return d.max()
+
+
+@pytest.mark.parametrize("use_aa", [1, 0])
+def test_mode9_render_matches_oracle_with_uploaded_crops(ofdg, oracle, use_aa):
+    """Mode 9 (non-rigid): identical warp crops on both sides (generated by the oracle,
+    uploaded through the C-ABI) -> masks, textures and flow re-sampled through them must
+    match bit for bit."""
+    W, H, B = 128, 96, 8
+    crops = oracle.warp_crops(W, H, seed=5)          # one seeded big field -> 40 crops
+    crops = crops[::5][:6] * 4.0                      # a few, amplified so that the warps are visible
+    g = make_gen(ofdg, W, H, 9, use_aa=use_aa, pool=(4, 256, 192))
+    g.warp_upload(crops)
+    assert g.warp_count() == len(crops)
+    pool = g.pool_download_all()
+    s = oracle.Sampler(9, W, H)
+    tasks, bps, n = s.next(B)
+    deform = sum(bps[t.background].do_warpfield_deformation for t in tasks) + \
+        sum(bps[t.first_object + i].do_warpfield_deformation for t in tasks for i in range(t.n_objects))
+    assert deform >= 10, "the test batch should exercise deformations"
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    prm = oracle.default_params(W, H, 9, use_aa)
+    e0, e1, ef = oracle.render(prm, tasks, B, bps, n, pool, warp_crops=crops, reuse=2)
+    assert np.array_equal(got[0], e0)
+    assert np.array_equal(got[1], e1), "image1 differs at %d px" % (got[1] != e1).sum()
+    assert nan_equal_ulp(got[2], ef) == 0
+    # the deformation is not a no-op: rigid rendering of the same blueprints differs
+    for i in range(n):
+        bps[i].do_warpfield_deformation = 0
+    r0, r1, rf = render_gpu(ofdg, g, tasks, B, bps, n)
+    assert np.array_equal(r0, e0) and not np.array_equal(r1, e1) and not np.array_equal(np.nan_to_num(rf), np.nan_to_num(ef))
+
+
+def test_mode9_field_generation_close_to_oracle(ofdg, oracle):
+    """Device warp-field generation (63-displacer analogue at small size, 17 self-composition
+    passes) vs the oracle: same seeded displacers; libm's expf differs in the last ulp
+    between host and device, so fields agree to a tolerance, not bitwise."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 9, pool=(2, 256, 192))
+    g.warp_generate(1, seed=11)
+    ref = oracle.warp_crops(W, H, seed=11)
+    assert g.warp_count() == len(ref)
+    worst = 0.0
+    for k in range(0, len(ref), 7):
+        c = g.warp_download(k)
+        assert np.array_equal(np.isnan(c), np.isnan(ref[k])) or (np.isnan(c) != np.isnan(ref[k])).mean() < 1e-3
+        ok = ~np.isnan(c) & ~np.isnan(ref[k])
+        worst = max(worst, float(np.abs(c[ok] - ref[k][ok]).max()))
+    assert worst < 2e-2, worst     # displacements are tens of pixels; agreement is ~1e-4 px
+
+
+def test_mode9_full_size_generated_fields(ofdg):
+    """BASELINE config 3 at full size: mode 9, 512x384, batch 32, 16 objects, device-generated
+    fields; properties: finite frames in range, idempotent re-render."""
+    torch = torch_mod()
+    W, H, B = 512, 384, 32
+    g = make_gen(ofdg, W, H, 9, num_objects=16, pool=(8, 1024, 768))
+    g.warp_generate(1, seed=3)
+    assert g.warp_count() == 40
+    tasks, bps, n = g.sample(B)
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    g.render(tasks, B, bps, n, i0, i1, fl)
+    g.synchronize()
+    a1 = i1.clone()
+    for t in (i0, i1):
+        assert float(t.min()) >= 0 and float(t.max()) <= 255 and torch.equal(t, t.round())
+    g.render_resident(i0, i1, fl)
+    g.synchronize()
+    assert torch.equal(a1, i1)

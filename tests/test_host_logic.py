@@ -240,3 +240,12 @@ def test_sharding_two_ranks_gloo(tmp_path, ofdg):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARDING_OK" in r.stdout
+
+
+def test_displacer_placement_equals_oracle(ofdg, oracle):
+    """Mode-9 displacer draws: hand-written mt19937 + distributions vs the oracle's <random>."""
+    for (W, H, seed) in ((512, 384, 0), (512, 384, 12345), (128, 96, 7), (1024, 768, 3)):
+        a = oracle.displacers(W, H, seed)
+        b = ofdg.host_displacers(W, H, seed)
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert len(oracle.displacers(512, 384, 1)) == 63  # 9 rows x 7 columns (SURVEY 3.5)

@@ -71,6 +71,8 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // conv_curve feeding rasterizer_scanline_aa::add_path (DG:465-479, 520-534),
 // agg::ellipse (100 steps), agg::curve3_div, ras_conv_int::upscale = iround(v*256).
 // --------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 16, kPx = 4;
+constexpr int kChunkW = 128;  // columns one raster item covers
 constexpr int kGeomWaves = 4;
 constexpr int kCurveSlots = 10;  // a polygon of <= 20 segments holds <= 9 curve3 segments
 
@@ -144,11 +146,10 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
                                                    const double* __restrict__ cs_tab, int W, int H,
                                                    DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
                                                    int4* __restrict__ obj_box, uint32_t* __restrict__ err,
-                                                   int* __restrict__ item_count,
+                                                   int* __restrict__ item_count, int4* __restrict__ items,
                                                    const DevCropRef* __restrict__ crops) {
   __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
   __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // consumed by bin_kernel (next launch)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
   if (sf >= n_shapes * 2) return;  // wave-uniform
@@ -220,86 +221,54 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
     if (overflow) atomicOr(err, kErrCurveCapacity);
   }
   minx = wave_min(minx); miny = wave_min(miny); maxx = wave_max(maxx); maxy = wave_max(maxy);
+  // AGG dx_limit: an edge spanning >= 16384 px takes a different code path in
+  // rasterizer_cells_aa::line; blueprints never get close, flag it if one does.
+  if (n_verts > 0 && ((long long)maxx - (long long)minx >= (16384LL << 8))) {
+    if (lane == 0) atomicOr(err, kErrDxLimit);
+    n_verts = 0;
+  }
+  int x0 = minx >> 8, y0 = miny >> 8, x1 = maxx >> 8, y1 = maxy >> 8;
+  const bool visible = !(n_verts < 2 || x1 < 0 || y1 < 0 || x0 > W - 1 || y0 > H - 1);
+  int bx0 = 1, by0 = 1, bx1 = 0, by1 = 0;  // box compose / raster work with (dilated for deforming shapes)
+  if (visible) {
+    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+    bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
+    if ((sf & 1) && S.deform > 0) {
+      // mode 9: the frame-1 mask is re-sampled through the inverse warp field, so it can
+      // reach max |iflow| (+ the bilinear footprint) beyond the outline's box
+      const int d = (int)ceilf(__uint_as_float(*crops[S.deform - 1].max_bits)) + 2;
+      bx0 = max(x0 - d, 0); by0 = max(y0 - d, 0); bx1 = min(x1 + d, W - 1); by1 = min(y1 + d, H - 1);
+    }
+  } else {
+    x0 = 1; x1 = 0; y0 = 1; y1 = 0;  // nothing on screen
+  }
   if (lane == 0) {
     DevShapeFrame f;
+    f.n_verts = n_verts;
+    f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
     f.pad[0] = f.pad[1] = f.pad[2] = 0;
-    // AGG dx_limit: an edge spanning >= 16384 px takes a different code path in
-    // rasterizer_cells_aa::line; blueprints never get close, flag it if one does.
-    if (n_verts > 0 && ((long long)maxx - (long long)minx >= (16384LL << 8))) {
-      atomicOr(err, kErrDxLimit);
-      n_verts = 0;
-    }
-    int x0 = minx >> 8, y0 = miny >> 8, x1 = maxx >> 8, y1 = maxy >> 8;
-    if (n_verts < 2 || x1 < 0 || y1 < 0 || x0 > W - 1 || y0 > H - 1) {
-      x0 = 1; x1 = 0; y0 = 1; y1 = 0;  // nothing on screen
-    } else {
-      x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
-      int bx0 = x0, by0 = y0, bx1 = x1, by1 = y1;
-      if ((sf & 1) && S.deform > 0) {
-        // mode 9: the frame-1 mask is re-sampled through the inverse warp field, so it can
-        // reach max |iflow| (+ the bilinear footprint) beyond the outline's box
-        const int d = (int)ceilf(__uint_as_float(*crops[S.deform - 1].max_bits)) + 2;
-        bx0 = max(x0 - d, 0); by0 = max(y0 - d, 0); bx1 = min(x1 + d, W - 1); by1 = min(y1 + d, H - 1);
-      }
+    frames[sf] = f;
+    if (visible) {
       int* box = reinterpret_cast<int*>(&obj_box[S.object * 2 + (sf & 1)]);  // union over the object's outlines, per frame
       atomicMin(box + 0, bx0); atomicMin(box + 1, by0); atomicMin(box + 2, -bx1); atomicMin(box + 3, -by1);
     }
-    f.n_verts = n_verts;
-    f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
-    frames[sf] = f;
   }
-}
-
-// --------------------------------------------------------------------------
-// bin_kernel: (a) per (sample, tile): bit mask of the foreground objects whose masks can
-// touch the tile (the object's box = union of the bounding boxes of all its outlines,
-// per frame, accumulated by geom_kernel), at the granularity of 64 x 8 blocks; (b) the
-// raster work list: for every outline of an on-screen object, one item per 8-row band x
-// 128-column chunk of the blocks the object's box touches in that frame -- so compose can
-// read the coverage of a touched block unmasked.
-// --------------------------------------------------------------------------
-constexpr int kTileW = 64, kTileH = 16, kPx = 4;
-constexpr int kChunkW = 128;  // columns one raster item covers
-
-__global__ __launch_bounds__(256) void bin_kernel(RenderDims dm, const DevSample* __restrict__ samples,
-                                                  const DevShape* __restrict__ shapes,
-                                                  const int4* __restrict__ obj_box,
-                                                  unsigned long long* __restrict__ tile_masks,
-                                                  int4* __restrict__ items, int* __restrict__ item_count) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int bands = (dm.H + kBandRows - 1) / kBandRows;
-  // (a) one thread per (sample, band, tile column, frame): object mask of that 64 x 8 block
-  const int n_mask_threads = dm.n_samples * bands * dm.tiles_x * 2;
-  if (gid < n_mask_threads) {
-    const int fr = gid & 1;
-    const int cell = gid >> 1;
-    const int tx = cell % dm.tiles_x;
-    const int band = (cell / dm.tiles_x) % bands;
-    const int s = cell / (dm.tiles_x * bands);
-    const int tx0 = tx * kTileW, by0 = band * kBandRows;
-    const DevSample smp = samples[s];
-    unsigned long long m = 0;
-    for (int oi = 1; oi < smp.n_objects; ++oi) {
-      const int4 b = obj_box[(smp.first_object + oi) * 2 + fr];  // {x0, y0, -x1, -y1}; empty: x0 > x1
-      if (b.x <= tx0 + kTileW - 1 && -b.z >= tx0 && b.y <= by0 + kBandRows - 1 && -b.w >= by0 && b.x <= -b.z)
-        m |= 1ull << (oi - 1);
+  // Raster work list: one item per 8-row band x 128-column chunk of the 64 x 8 blocks the
+  // (dilated) box touches.  Coverage outside these blocks is never read: compose tests the
+  // block against the same box.
+  if (visible) {
+    const int band0 = by0 / kBandRows, band1 = by1 / kBandRows;
+    const int xa = (bx0 / kTileW) * kTileW, xb = min((bx1 / kTileW) * kTileW + kTileW - 1, W - 1);
+    const int nchunks = (xb - xa + kChunkW) / kChunkW;
+    const int n_items = (band1 - band0 + 1) * nchunks;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(item_count, n_items);
+    base = __shfl(base, 0, 64);
+    for (int i = lane; i < n_items; i += 64) {
+      const int b = band0 + i / nchunks, cx = xa + (i % nchunks) * kChunkW;
+      items[base + i] = make_int4(sf, b, cx, min(cx + kChunkW - 1, xb));
     }
-    tile_masks[gid] = m;
-    return;
   }
-  // (b) raster items: one thread per (shape-frame, band of kBandRows rows)
-  const int j = gid - n_mask_threads;
-  if (j >= dm.n_shapes * 2 * bands) return;
-  const int sf = j / bands, band = j - sf * bands;
-  const int4 b = obj_box[shapes[sf >> 1].object * 2 + (sf & 1)];
-  const int x0 = b.x, y0 = b.y, x1 = -b.z, y1 = -b.w;
-  if (x0 > x1) return;
-  const int by0 = band * kBandRows;
-  if (by0 + kBandRows - 1 < y0 || by0 > y1) return;
-  const int xa = (x0 / kTileW) * kTileW, xb = min((x1 / kTileW) * kTileW + kTileW - 1, dm.W - 1);
-  const int nchunks = (xb - xa + kChunkW) / kChunkW;
-  int at = atomicAdd(item_count, nchunks);
-  for (int cx = xa; cx <= xb; cx += kChunkW) items[at++] = make_int4(sf, band, cx, min(cx + kChunkW - 1, xb));
 }
 
 // --------------------------------------------------------------------------
@@ -544,7 +513,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const DevShapeFrame* __rest
   __shared__ __attribute__((aligned(16))) ChunkCells s_cells[kRasterWaves];
   __shared__ int s_queue[kRasterWaves][64 * kBandRows];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // bin_kernel (previous launch) has consumed the object boxes: empty them for the next batch
+  // empty the object boxes the NEXT launch of this slot accumulates into (the other parity)
   {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n_objects * 2) obj_box[gid] = make_int4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
@@ -800,13 +769,15 @@ __device__ __forceinline__ int lerp_u8(const Taps& t, float Icc, float Inc, floa
 template <bool kDeform>
 __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
                                              const DevObject* __restrict__ objects,
-                                             const unsigned long long* __restrict__ tile_masks,
+                                             const int4* __restrict__ obj_box,
                                              const uint8_t* __restrict__ cov,
                                              const uint32_t* __restrict__ pool,
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops) {
+                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  // raster_kernel has consumed the work list: reset the counter for this slot's next launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
   // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give
   // every XCD a contiguous run of tiles (whole samples): their background rows,
   // coverage slots and object records then stay in that XCD's L2.
@@ -828,34 +799,27 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
 
   const DevSample smp = samples[s];
   const DevObject* objs = objects + smp.first_object;
-  // every wave covers 4 rows: waves 0,1 the upper 64 x 8 block of the tile, waves 2,3 the lower
-  const int bands = (H + kBandRows - 1) / kBandRows;
-  const int band = __builtin_amdgcn_readfirstlane(ty0 / kBandRows + (int)(threadIdx.x >> 7));
-  unsigned long long mask0 = 0, mask1 = 0;
-  if (band < bands) {
-    const size_t mi = (((size_t)s * bands + band) * dm.tiles_x + (t % dm.tiles_x)) * 2;
-    mask0 = tile_masks[mi];
-    mask1 = tile_masks[mi + 1];
+  // Every wave covers 4 rows: waves 0,1 the upper 64 x 8 block of the tile, waves 2,3 the
+  // lower.  Which objects can touch the block: lane l tests object l's per-frame box
+  // (accumulated by geom_kernel) and a ballot turns the answers into the bit masks.
+  unsigned long long mask0, mask1;
+  {
+    const int by0 = __builtin_amdgcn_readfirstlane(ty0 + (int)(threadIdx.x >> 7) * kBandRows);
+    const int lane = threadIdx.x & 63;
+    bool t0 = false, t1 = false;
+    if (lane + 1 < smp.n_objects) {
+      const int4* bx = obj_box + (size_t)(smp.first_object + 1 + lane) * 2;
+      const int4 b0 = bx[0], b1 = bx[1];  // {x0, y0, -x1, -y1}; empty: x0 > x1
+      t0 = b0.x <= tx0 + kTileW - 1 && -b0.z >= tx0 && b0.y <= by0 + kBandRows - 1 && -b0.w >= by0 && b0.x <= -b0.z;
+      t1 = b1.x <= tx0 + kTileW - 1 && -b1.z >= tx0 && b1.y <= by0 + kBandRows - 1 && -b1.w >= by0 && b1.x <= -b1.z;
+    }
+    mask0 = __ballot(t0);
+    mask1 = __ballot(t1);
   }
   unsigned long long omask = mask0 | mask1;
 
   const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
   const size_t slot_bytes = (size_t)W * H;
-  // Coverage of the next simple object is requested one iteration ahead, so its memory
-  // round trip overlaps the texture fetches and blends of the current object.
-  uint32_t nc0 = 0, nc1 = 0;
-  auto prefetch = [&](unsigned long long m) {
-    nc0 = 0; nc1 = 0;
-    if (m == 0) return;
-    const int oj = __ffsll((long long)m);
-    const DevObject& N = objs[oj];
-    if (N.kind != 1 || !inside) return;
-    const uint8_t* c = cov + (size_t)N.first_shape * 2 * slot_bytes;
-    if ((mask0 >> (oj - 1)) & 1ull) nc0 = *reinterpret_cast<const uint32_t*>(c + pix);
-    if ((mask1 >> (oj - 1)) & 1ull) nc1 = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
-  };
-  prefetch(omask);
-
   uint32_t px0[kPx], px1[kPx];  // frames, packed B | G<<8 | R<<16
   float fu[kPx], fv[kPx];
 
@@ -987,8 +951,12 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
     };
 
     if (O.kind == 1) {
-      const uint32_t c0w = nc0, c1w = nc1;
-      prefetch(omask);
+      const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
+      uint32_t c0w = 0, c1w = 0;
+      if (inside) {
+        if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+        if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+      }
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
@@ -1016,8 +984,15 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
         const uint8_t* c = cov + (size_t)(O.first_shape + k) * 2 * slot_bytes;
         uint32_t c0w = 0, c1w = 0;
         if (inside) {
-          if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
-          if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+          // a component's coverage exists only in the 64 x 8 blocks its own box touches
+          const int by0c = ty0 + (int)(threadIdx.x >> 7) * kBandRows;
+          const DevShapeFrame F0 = frames[(O.first_shape + k) * 2], F1 = frames[(O.first_shape + k) * 2 + 1];
+          int d1 = 0;
+          if constexpr (kDeform) { if (O.deform > 0) d1 = (int)ceilf(__uint_as_float(*crops[O.deform - 1].max_bits)) + 2; }
+          const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
+          const bool v1 = F1.x0 <= F1.x1 && F1.x0 - d1 <= tx0 + kTileW - 1 && F1.x1 + d1 >= tx0 && F1.y0 - d1 <= by0c + kBandRows - 1 && F1.y1 + d1 >= by0c;
+          if (has0 && v0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+          if (has1 && v1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
         }
         const bool additive = (O.additive >> k) & 1u;
 #pragma unroll
@@ -1044,18 +1019,19 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
         m0[p] = dm.use_aa ? ua0[p] : na0[p];
         m1[p] = dm.use_aa ? ua1[p] : un1[p];
       }
-      prefetch(omask);
     }
 
     const int any0 = m0[0] | m0[1] | m0[2] | m0[3];
     const int any1 = m1[0] | m1[1] | m1[2] | m1[3];
     const int anyn = na0[0] | na0[1] | na0[2] | na0[3];
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
-    // issue every texture fetch of this object before the first blend waits on one
-    uint4 q0 = make_uint4(0, 0, 0, 0);
+    if (any0) {  // frame 0 texture: identity warp == the crop itself (DG:339-340)
+      const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
+      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
+    }
     uint32_t t1[kPx] = {0, 0, 0, 0};
-    if (any0)  // frame 0 texture: identity warp == the crop itself (DG:339-340)
-      q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
     bool deform_tex = false;
     if constexpr (kDeform) deform_tex = (O.deform > 0);
     if (any1 && !deform_tex) {
@@ -1097,11 +1073,6 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
           t1[p] = o;
         }
       }
-    }
-    if (any0) {
-      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
     }
     if (any1) {
 #pragma unroll
@@ -1149,21 +1120,20 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
 }
 
-// At most 4 waves per SIMD: compose is bandwidth-bound well before that, and the spare
-// registers let the (latency-bound) preparation kernels of the next batch co-reside.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose_kernel(
+__global__ __launch_bounds__(256) void compose_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const unsigned long long* __restrict__ tile_masks, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow) {
-  compose_body<false>(dm, samples, objects, tile_masks, cov, pool, img0, img1, flow, nullptr, nullptr);
+    const int4* __restrict__ obj_box, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+  compose_body<false>(dm, samples, objects, obj_box, cov, pool, img0, img1, flow, frames, nullptr, item_count);
 }
 // Mode 9: the same kernel with the deformation paths compiled in.
 __global__ __launch_bounds__(256) void compose_deform_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const unsigned long long* __restrict__ tile_masks, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const int4* __restrict__ obj_box, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops) {
-  compose_body<true>(dm, samples, objects, tile_masks, cov, pool, img0, img1, flow, frames, crops);
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_body<true>(dm, samples, objects, obj_box, cov, pool, img0, img1, flow, frames, crops, item_count);
 }
 
 // --------------------------------------------------------------------------

@@ -58,10 +58,11 @@ struct ofdg_ctx {
     DevBuf<int2> d_verts;
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
-    DevBuf<unsigned long long> d_tile_masks;
     DevBuf<int4> d_items;
-    DevBuf<int4> d_obj_box;
+    DevBuf<int4> d_obj_box;  // [2 parities][objects][2 frames]
     int res_objects = 0;
+    int box_parity = 0;
+    size_t box_stride = 0;   // int4 elements per parity
     hipEvent_t ev_uploaded = nullptr;
     bool upload_pending = false;
     DevBuf<DevCropRef> d_croptab;      // mode 9: crops of this batch's deforming objects
@@ -170,7 +171,11 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  if ((e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking)) != hipSuccess) {
+  // the preparation kernels are tiny and on the critical path of the next compose: give
+  // their stream the highest priority so that their workgroups are dispatched first
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if ((e = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
@@ -201,7 +206,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
-    sl.d_tile_masks.release(); sl.d_items.release(); sl.d_obj_box.release();
+    sl.d_items.release(); sl.d_obj_box.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
@@ -326,7 +331,6 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
-  const int bands = (H + kBandRows - 1) / kBandRows;
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
     ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
@@ -345,22 +349,20 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     if (c->compose_pending[cb]) HIP_OK(c, hipStreamWaitEvent(ps, c->ev_compose_done[cb], 0));
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
-  // geom: outlines + bounding boxes (also zeroes the raster item counter)
+  // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
+  const int bp = sl.box_parity;
+  sl.box_parity ^= 1;
+  int4* box_cur = sl.d_obj_box.p + (size_t)bp * sl.box_stride;
+  int4* box_next = sl.d_obj_box.p + (size_t)(bp ^ 1) * sl.box_stride;
   hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(256), 0, ps, sl.d_shapes.p,
-                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, sl.d_obj_box.p, c->d_err, sl.d_item_count, sl.d_croptab.p);
+                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count,
+                     sl.d_items.p, sl.d_croptab.p);
   HIP_OK(c, hipGetLastError());
-  // bin: block -> object masks, raster work list
-  {
-    const int threads = dm.n_samples * bands * dm.tiles_x * 2 + n_sf * bands;
-    hipLaunchKernelGGL(bin_kernel, dim3((threads + 255) / 256), dim3(256), 0, ps, dm, sl.d_samples.p, sl.d_shapes.p,
-                       sl.d_obj_box.p, sl.d_tile_masks.p, sl.d_items.p, sl.d_item_count);
-    HIP_OK(c, hipGetLastError());
-  }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
     hipLaunchKernelGGL(raster_kernel, dim3(rgrid), dim3(256), 0, ps, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
-                       sl.d_verts.p, W, H, cov, sl.d_obj_box.p, sl.res_objects);
+                       sl.d_verts.p, W, H, cov, box_next, sl.res_objects);
     HIP_OK(c, hipGetLastError());
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[2], ps));
@@ -371,11 +373,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
   if (c->prm.mode == 9)
     hipLaunchKernelGGL(compose_deform_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm,
-                       sl.d_samples.p, sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow,
-                       sl.d_frames.p, sl.d_croptab.p);
+                       sl.d_samples.p, sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow,
+                       sl.d_frames.p, sl.d_croptab.p, sl.d_item_count);
   else
+    // compose_kernel allocates 104 VGPRs -> 4 waves per SIMD; the remaining 96 registers per
+    // lane and all of the LDS are what lets the latency-bound preparation kernels of the
+    // next batch (internal stream) co-reside with it.
     hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
-                       sl.d_objects.p, sl.d_tile_masks.p, cov, c->pool, d_img0, d_img1, d_flow);
+                       sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
   if (c->overlap) {
@@ -413,15 +418,19 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     }
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
     (void)tiles;
-    HIP_OK(c, sl.d_tile_masks.reserve((size_t)n_tasks * ((H + kBandRows - 1) / kBandRows) * ((W + kTileW - 1) / kTileW) * 2));
     HIP_OK(c, sl.d_items.reserve(n_shapes * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
-    if (n_obj * 2 > sl.d_obj_box.cap) {
+    if (n_obj * 2 > sl.box_stride) {
       HIP_OK(c, hipDeviceSynchronize());
-      HIP_OK(c, sl.d_obj_box.reserve(n_obj * 2));
-      // emptied once here; afterwards raster_kernel re-empties the boxes every launch
+      sl.box_stride = n_obj * 2 + n_obj / 2 + 16;
+      HIP_OK(c, sl.d_obj_box.reserve(sl.box_stride * 2));
+      sl.box_stride = sl.d_obj_box.cap / 2;
+      // emptied once here; afterwards raster_kernel re-empties the other parity every launch
       HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
     }
-    if (!sl.d_item_count) HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
+    if (!sl.d_item_count) {
+      HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
+      HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
+    }
   }
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n_tasks));
@@ -715,7 +724,8 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   const int n_items = (int)items.size();
   HIP_OK(c, sl.d_items.reserve(items.size()));
   if (sl.d_obj_box.cap == 0) {
-    HIP_OK(c, sl.d_obj_box.reserve(1));
+    HIP_OK(c, sl.d_obj_box.reserve(32));
+    sl.box_stride = sl.d_obj_box.cap / 2;
     HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
   }
   if (!sl.d_item_count) HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
@@ -725,6 +735,7 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
                      W, H, c->d_cov2[0].p, sl.d_obj_box.p, 0);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipMemcpy(coverage_host, c->d_cov2[0].p, (size_t)W * H, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
   for (auto& s2 : c->slots) s2.res_samples = 0;  // the workspaces no longer hold a rendered batch
   return OFDG_OK;
 }

@@ -177,6 +177,19 @@ int ofdg_render_slot(ofdg_ctx* ctx, int slot, float* d_image0, float* d_image1,
 int ofdg_forward(ofdg_ctx* ctx, float* d_image0, float* d_image1, float* d_flow,
                  void* stream);
 
+/* Device counter-based sampler (OFDG_SAMPLER_COUNTER): the sampling half of load_batch
+ * (LAY:197-213) on the GPU.  Sample g is a pure function of (seed, g); same modes and
+ * distributions as the reference stream, statistically (not bitwise) equal to it.
+ * ofdg_forward_counter samples + renders global indices first_index .. first_index+n-1
+ * with no host data in the loop (ofdg_forward uses it when params.sampler is COUNTER:
+ * rank r takes indices step*B*world + r*B + [0,B)).  ofdg_sample_counter downloads the
+ * blueprints instead (fixed layout: 257 per sample = background, 32 object slots,
+ * 32 x 7 component slots; unused slots have obj_type 0). */
+int ofdg_forward_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
+                         float* d_image0, float* d_image1, float* d_flow, void* stream);
+int ofdg_sample_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
+                        ofdg_task* tasks, ofdg_blueprint* bps);
+
 /* Wait for `stream` and report device-side error flags raised by kernels. */
 int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
 

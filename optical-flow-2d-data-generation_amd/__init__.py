@@ -73,7 +73,7 @@ EXPORTS = [
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
-    "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
+    "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
 ]
@@ -125,6 +125,8 @@ def lib():
         L.ofdg_debug_tables.argtypes = [vp, vp, vp, vp, vp, i32]
         L.ofdg_set_profiling.argtypes = [vp, i32]
         L.ofdg_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+        L.ofdg_forward_counter.argtypes = [vp, C.c_longlong, i32, vp, vp, vp, vp]
+        L.ofdg_sample_counter.argtypes = [vp, C.c_longlong, i32, vp, vp]
         L.ofdg_warp_generate.argtypes = [vp, i32, C.c_uint32]
         L.ofdg_warp_upload.argtypes = [vp, vp, i32]
         L.ofdg_warp_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -234,6 +236,16 @@ class Generator:
 
     def forward(self, img0, img1, flow, stream=0):
         self._check(lib().ofdg_forward(self.h, _dptr(img0), _dptr(img1), _dptr(flow), C.c_void_p(stream)))
+
+    def forward_counter(self, first_index, n, img0, img1, flow, stream=0):
+        self._check(lib().ofdg_forward_counter(self.h, first_index, n, _dptr(img0), _dptr(img1), _dptr(flow), C.c_void_p(stream)))
+
+    def sample_counter(self, first_index, n):
+        """Blueprints of the device counter sampler: (tasks, bps, n_bps) in the fixed layout."""
+        tasks = (Task * n)()
+        bps = (Blueprint * (n * 257))()
+        self._check(lib().ofdg_sample_counter(self.h, first_index, n, C.cast(tasks, C.c_void_p), C.cast(bps, C.c_void_p)))
+        return tasks, bps, n * 257
 
     def synchronize(self, stream=0):
         self._check(lib().ofdg_synchronize(self.h, C.c_void_p(stream)))

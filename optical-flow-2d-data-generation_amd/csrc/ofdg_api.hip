@@ -15,6 +15,7 @@
 
 #include "../../include/ofdg.h"
 #include "kernels.hip"
+#include "sampler_counter.hip"
 #include "ofdg_device.h"
 #include "realize.h"
 #include "sampler_ref.h"
@@ -79,6 +80,12 @@ struct ofdg_ctx {
   size_t h_stage_bytes = 0;
   hipEvent_t stage_free = nullptr;
   bool stage_pending = false;
+  // device counter sampler (OFDG_SAMPLER_COUNTER)
+  CsMode cs_mode;
+  DevBuf<ofdg_blueprint> d_cs_bps;
+  DevBuf<int> d_cs_nobj;
+  int* d_cs_nshapes = nullptr;
+  long long next_index = 0;  // next global sample index of this rank's stream
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
   float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
@@ -155,6 +162,36 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   if (c->prm.world_size < 1) c->prm.world_size = 1;
   c->sampler.reset(new RefSampler(params->mode, params->width, params->height, params->num_objects));
   if (!c->sampler->ok()) { g_create_error = "BAD MODE"; return OFDG_EBADMODE; }
+  {  // constants of the device counter sampler: the 13 mode tables as deltas to mode 7 (DG:1363-2001)
+    CsMode& M = c->cs_mode;
+    const double pi = 3.14159265358979323846;
+    struct Mag { double bg_rot, bg_trans, bg_s0, bg_s1, obj_trans, obj_rot, obj_s0, obj_s1, t_bgr, t_bgs, t_or, t_os; };
+    Mag g{10, 40, 0.93, 1.07, 120, 30, 0.8, 1.2, 0.3, 0.6, 0.7, 0.7};
+    const int mode = params->mode;
+    if (mode == 10) g = Mag{5, 20, 0.965, 1.035, 60, 15, 0.9, 1.1, 0.176, 0.429, 0.539, 0.539};
+    if (mode == 11) g = Mag{20, 80, 0.86, 1.14, 240, 60, 0.6, 1.4, 0.462, 0.75, 0.824, 0.824};
+    if (mode == 12) g = Mag{3.3, 13.3, 0.976, 1.023, 40, 10, 0.933, 1.066, 0.125, 0.333, 0.437, 0.437};
+    if (mode == 13) g = Mag{30, 120, 0.79, 1.21, 360, 90, 0.4, 1.6, 0.563, 0.818, 0.875, 0.875};
+    const bool tonly = (mode == 1 || mode == 2 || mode == 3 || mode == 8);
+    const bool rot = !tonly, scl = !tonly && mode != 4;
+    M.bg_rot_a = rot ? (float)(-g.bg_rot * pi / 180.) : 0.f; M.bg_rot_b = rot ? (float)(g.bg_rot * pi / 180.) : 0.f;
+    M.bg_trans = (float)g.bg_trans;
+    M.bg_scale_a = scl ? (float)g.bg_s0 : 1.f; M.bg_scale_b = scl ? (float)g.bg_s1 : 1.f;
+    M.t_bg_rot = rot ? (float)g.t_bgr : -1.f; M.t_bg_scale = scl ? (float)g.t_bgs : -1.f;
+    M.t_obj_rot = rot ? (float)g.t_or : -1.f; M.t_obj_scale = scl ? (float)g.t_os : -1.f;
+    M.obj_trans = (float)g.obj_trans;
+    M.obj_rot_a = rot ? (float)(-g.obj_rot * pi / 180.) : 0.f; M.obj_rot_b = rot ? (float)(g.obj_rot * pi / 180.) : 0.f;
+    M.obj_scale_a = scl ? (float)g.obj_s0 : 1.f; M.obj_scale_b = scl ? (float)g.obj_s1 : 1.f;
+    M.init_rot_a = mode == 1 ? 0.f : (float)-pi; M.init_rot_b = mode == 1 ? 0.f : (float)pi;
+    M.deform_thr = mode == 9 ? 0.2f : 0.f;
+    M.type_mask = (mode == 1 || mode == 2) ? 2 : mode == 3 ? 1 : (mode == 4 || mode == 5 || mode == 8) ? 3 : 7;
+    M.n_types = 0;
+    if (M.type_mask & 1) M.types[M.n_types++] = OFDG_OBJ_ELLIPSE;
+    if (M.type_mask & 2) M.types[M.n_types++] = OFDG_OBJ_POLYGON;
+    if (M.type_mask & 4) M.types[M.n_types++] = OFDG_OBJ_COMPOSITE;
+    M.mode = mode; M.W = params->width; M.H = params->height; M.num_objects = params->num_objects;
+    M.seed = (uint32_t)params->seed;
+  }
   // cos/sin of agg::ellipse's 100 step angles, from the host libm
   double tab[200];
   const double pi = 3.14159265358979323846;
@@ -223,6 +260,8 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
   if (c->d_warp) (void)hipFree(c->d_warp);
   if (c->d_warp_max) (void)hipFree(c->d_warp_max);
+  c->d_cs_bps.release(); c->d_cs_nobj.release();
+  if (c->d_cs_nshapes) (void)hipFree(c->d_cs_nshapes);
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
@@ -321,7 +360,8 @@ int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps,
 }
 
 // ---- render -------------------------------------------------------------------------------
-static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
+static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st,
+                           long long cs_first_index = -1) {
   const int W = c->prm.width, H = c->prm.height;
   const int n_sf = sl.res_shapes * 2;
   RenderDims dm;
@@ -349,6 +389,18 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     if (c->compose_pending[cb]) HIP_OK(c, hipStreamWaitEvent(ps, c->ev_compose_done[cb], 0));
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
+  const int* n_shapes_dev = nullptr;
+  if (cs_first_index >= 0) {
+    // device counter sampler + device realize feed the slot's records (no host data)
+    hipLaunchKernelGGL(cs_sample_kernel, dim3(sl.res_samples), dim3(256), 0, ps, c->cs_mode, cs_first_index, sl.res_samples,
+                       c->d_cs_bps.p, c->d_cs_nobj.p);
+    HIP_OK(c, hipGetLastError());
+    CsRealizeDims D{W, H, c->pool_n, c->pool_w, c->pool_h, sl.res_samples};
+    hipLaunchKernelGGL(cs_realize_kernel, dim3(1), dim3(1024), 0, ps, D, c->d_cs_bps.p, c->d_cs_nobj.p, sl.d_shapes.p,
+                       sl.d_objects.p, sl.d_samples.p, c->d_cs_nshapes, sl.res_shapes, c->d_err);
+    HIP_OK(c, hipGetLastError());
+    n_shapes_dev = c->d_cs_nshapes;
+  }
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
   sl.box_parity ^= 1;
@@ -356,7 +408,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   int4* box_next = sl.d_obj_box.p + (size_t)(bp ^ 1) * sl.box_stride;
   hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(256), 0, ps, sl.d_shapes.p,
                      sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count,
-                     sl.d_items.p, sl.d_croptab.p);
+                     sl.d_items.p, sl.d_croptab.p, n_shapes_dev);
   HIP_OK(c, hipGetLastError());
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
   {
@@ -551,8 +603,93 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
   return ofdg_render_slot(c, 0, d_img0, d_img1, d_flow, stream);
 }
 
+// size slot `sl` for n device-sampled samples (upper bounds; the kernels read the actual
+// shape count from device memory)
+static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
+  if (c->prm.mode == 9) { c->err = "the counter sampler does not support mode 9 yet (use the ref sampler)"; return OFDG_EINVAL; }
+  if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
+  if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
+  const int W = c->prm.width, H = c->prm.height;
+  const size_t shapes_cap = (size_t)n * (c->prm.mode >= 6 ? 96 : kCsMaxObjects);
+  const size_t n_obj = (size_t)n * (1 + kCsMaxObjects);
+  HIP_OK(c, c->d_cs_bps.reserve((size_t)n * kCsBlueprintsPerSample));
+  HIP_OK(c, c->d_cs_nobj.reserve(n));
+  if (!c->d_cs_nshapes) HIP_OK(c, hipMalloc((void**)&c->d_cs_nshapes, sizeof(int)));
+  HIP_OK(c, sl.d_shapes.reserve(shapes_cap + 8));  // (+ slack: a composite may overshoot the estimate, see below)
+  HIP_OK(c, sl.d_frames.reserve(shapes_cap * 2));
+  HIP_OK(c, sl.d_verts.reserve(shapes_cap * 2 * kMaxVerts));
+  HIP_OK(c, sl.d_objects.reserve(n_obj));
+  HIP_OK(c, sl.d_samples.reserve(n));
+  const size_t need_cov = shapes_cap * 2 * (size_t)W * H + 16;
+  if (need_cov > c->d_cov2[0].cap) {
+    HIP_OK(c, hipDeviceSynchronize());
+    HIP_OK(c, c->d_cov2[0].reserve(need_cov));
+    HIP_OK(c, c->d_cov2[1].reserve(need_cov));
+  }
+  HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
+  if (n_obj * 2 > sl.box_stride) {
+    HIP_OK(c, hipDeviceSynchronize());
+    sl.box_stride = n_obj * 2 + 16;
+    HIP_OK(c, sl.d_obj_box.reserve(sl.box_stride * 2));
+    sl.box_stride = sl.d_obj_box.cap / 2;
+    HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
+  }
+  if (!sl.d_item_count) {
+    HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
+    HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
+  }
+  sl.res_samples = n;
+  sl.res_shapes = (int)shapes_cap;  // launch bound; the kernels use the device-side count
+  sl.res_objects = (int)n_obj;
+  sl.batch.samples.clear();
+  return OFDG_OK;
+}
+
+// Sample n_samples blueprints with global indices first_index.. on the DEVICE (counter
+// sampler: a sample is a pure function of (seed, global index)) and render them.
+int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
+                         void* stream) {
+  if (!c || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
+  // alternate between two slots so that consecutive launches overlap
+  ofdg_ctx::Slot& sl = c->slots[ofdg_ctx::kSlots - 1 - (int)(c->launch_count & 1)];
+  int rc = prepare_counter_slot(c, sl, n_samples);
+  if (rc != OFDG_OK) return rc;
+  return launch_resident(c, sl, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
+}
+
+// Download the blueprints the counter sampler produces for samples first_index.. (tests):
+// tasks[n], bps[n * 257] in the fixed per-sample layout (background, 32 object slots, 32 x 7
+// component slots); unused slots have obj_type 0.
+int ofdg_sample_counter(ofdg_ctx* c, long long first_index, int n_samples, ofdg_task* tasks, ofdg_blueprint* bps) {
+  if (!c || !tasks || !bps || n_samples < 1 || first_index < 0) return OFDG_EINVAL;
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, c->d_cs_bps.reserve((size_t)n_samples * kCsBlueprintsPerSample));
+  HIP_OK(c, c->d_cs_nobj.reserve(n_samples));
+  hipLaunchKernelGGL(cs_sample_kernel, dim3(n_samples), dim3(256), 0, 0, c->cs_mode, first_index, n_samples, c->d_cs_bps.p,
+                     c->d_cs_nobj.p);
+  HIP_OK(c, hipGetLastError());
+  std::vector<int> nobj(n_samples);
+  HIP_OK(c, hipMemcpy(bps, c->d_cs_bps.p, (size_t)n_samples * kCsBlueprintsPerSample * sizeof(ofdg_blueprint), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(nobj.data(), c->d_cs_nobj.p, n_samples * sizeof(int), hipMemcpyDeviceToHost));
+  for (int s = 0; s < n_samples; ++s) {
+    tasks[s].background = s * kCsBlueprintsPerSample;
+    tasks[s].first_object = s * kCsBlueprintsPerSample + 1;
+    tasks[s].n_objects = nobj[s];
+    tasks[s].reserved = 0;
+  }
+  return OFDG_OK;
+}
+
 int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
   if (!c) return OFDG_EINVAL;
+  if (c->prm.sampler == OFDG_SAMPLER_COUNTER) {
+    // rank r owns global indices step*B*world + r*B + [0, B)
+    const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
+    if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
+    const long long first = c->step * (long long)B * world + (long long)rank * B;
+    c->step++;
+    return ofdg_forward_counter(c, first, B, d_img0, d_img1, d_flow, stream);
+  }
   const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
   if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
   // every rank walks the identical sequential stream and keeps its own block of

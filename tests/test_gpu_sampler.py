@@ -1,0 +1,136 @@
+"""GPU tests of the device counter-based sampler (OFDG_SAMPLER_COUNTER): determinism and
+index purity, statistical equivalence with the reference stream (it is not bitwise equal
+by design), and end-to-end rendering of device-sampled blueprints against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fields(bps, tasks):
+    """Per top-level object: dict of arrays."""
+    out = {k: [] for k in ("type", "init_rot", "init_tx", "init_ty", "rot", "scale", "tx", "ty", "ncomp", "ex", "nseg")}
+    nobj = []
+    bg = {k: [] for k in ("rot", "scale", "tx", "ty")}
+    for t in tasks:
+        nobj.append(t.n_objects)
+        b = bps[t.background]
+        bg["rot"].append(b.rot); bg["scale"].append(b.scale); bg["tx"].append(b.trans_x); bg["ty"].append(b.trans_y)
+        for i in range(t.n_objects):
+            o = bps[t.first_object + i]
+            out["type"].append(o.obj_type); out["init_rot"].append(o.init_rot)
+            out["init_tx"].append(o.init_trans_x); out["init_ty"].append(o.init_trans_y)
+            out["rot"].append(o.rot); out["scale"].append(o.scale); out["tx"].append(o.trans_x); out["ty"].append(o.trans_y)
+            out["ncomp"].append(o.n_components); out["ex"].append(o.ellipse_scale_x); out["nseg"].append(o.n_segments)
+    return {k: np.array(v) for k, v in out.items()}, np.array(nobj), {k: np.array(v) for k, v in bg.items()}
+
+
+def ks(a, b):
+    from scipy.stats import ks_2samp
+    return ks_2samp(a, b).pvalue
+
+
+@pytest.mark.parametrize("mode", [5, 7])
+def test_counter_sampler_statistics_match_reference_stream(ofdg, mode):
+    W, H, N = 512, 384, 600
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=mode, sampler=1, seed=1234))
+    tasks, bps, n = g.sample_counter(0, N)
+    rt, rb, rn = ofdg.HostSampler(mode, W, H).next(N, cap=N * 300)
+    a, na, bga = fields(bps, tasks)
+    b, nb, bgb = fields(rb, rt)
+    # number of objects: uniform on 16..23
+    assert set(np.unique(na)) <= set(range(16, 24)) and abs(na.mean() - nb.mean()) < 0.4
+    # type frequencies
+    for t in (1, 2, 3):
+        assert abs((a["type"] == t).mean() - (b["type"] == t).mean()) < 0.03
+    # continuous fields: two-sample KS
+    for k in ("init_rot", "init_tx", "init_ty", "tx", "ty"):
+        assert ks(a[k], b[k]) > 1e-3, k
+    for k in ("rot", "scale"):  # point mass at 0 / 1 (trigger) + shaped Gaussian
+        assert abs((a[k] == (0 if k == "rot" else 1)).mean() - (b[k] == (0 if k == "rot" else 1)).mean()) < 0.03, k
+        fa, fb = a[k][a[k] != (0 if k == "rot" else 1)], b[k][b[k] != (0 if k == "rot" else 1)]
+        assert ks(fa, fb) > 1e-3, k
+    for k in ("rot", "scale", "tx", "ty"):
+        assert ks(bga[k], bgb[k]) > 1e-4, "bg " + k
+    el = a["type"] == 1
+    assert ks(a["ex"][el], b["ex"][b["type"] == 1]) > 1e-3      # incl. the 0.05x "needle" mass in mode 7
+    po = a["type"] == 2
+    assert abs(a["nseg"][po].mean() - b["nseg"][b["type"] == 2].mean()) < 0.5
+    if mode == 7:
+        co = a["type"] == 3
+        assert abs(a["ncomp"][co].mean() - b["ncomp"][b["type"] == 3].mean()) < 0.3
+
+
+def test_counter_sampler_is_a_pure_function_of_the_index(ofdg):
+    W, H = 512, 384
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=9))
+    t1, b1, _ = g.sample_counter(100, 8)
+    t2, b2, _ = g.sample_counter(104, 8)   # overlaps indices 104..107
+    sz = C.sizeof(ofdg.Blueprint)
+    fc = ofdg.Blueprint.first_component.offset // 4
+
+    def live(bps, s, n_obj):
+        """bytes of the live blueprints of sample s (unused slots hold stale data)."""
+        a = np.frombuffer(C.string_at(C.addressof(bps) + s * 257 * sz, 257 * sz), np.int32).reshape(257, -1).copy()
+        a[:, fc] = 0  # component indices are positions in the batch array
+        rows = [0] + [1 + o for o in range(n_obj)]
+        for o in range(n_obj):
+            b = bps[s * 257 + 1 + o]
+            if b.obj_type == 3:
+                rows += [1 + 32 + o * 7 + k for k in range(b.n_components)]
+        return a[rows]
+
+    for k in range(4):
+        assert t1[4 + k].n_objects == t2[k].n_objects
+        assert np.array_equal(live(b1, 4 + k, t1[4 + k].n_objects), live(b2, k, t2[k].n_objects))
+    g2 = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=10))
+    t3, b3, _ = g2.sample_counter(100, 1)
+    assert not np.array_equal(live(b3, 0, t3[0].n_objects)[:17], live(b1, 0, t1[0].n_objects)[:17])   # the seed matters
+
+
+@pytest.mark.parametrize("mode", [5, 7])
+def test_counter_forward_matches_oracle_on_its_own_blueprints(ofdg, oracle, mode):
+    """forward_counter = device sampling + device realize (device sin/cos) + render.  The
+    oracle renders the downloaded blueprints with host libm: frames within 1 LSB and flow
+    within 1 ULP (north-star tolerance), and all but a vanishing fraction identical."""
+    import torch
+    W, H, B = 128, 96, 6
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=mode, sampler=1, seed=77))
+    g.pool_synthetic(4, 256, 192, 5)
+    pool = g.pool_download_all()
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    g.forward_counter(40, B, i0, i1, fl)
+    g.synchronize()
+    tasks, bps, n = g.sample_counter(40, B)
+    e0, e1, ef = oracle.render(oracle.default_params(W, H, mode), tasks, B, bps, n, pool)
+    g0, g1, gf = i0.cpu().numpy(), i1.cpu().numpy(), fl.cpu().numpy()
+    for got, exp in ((g0, e0), (g1, e1)):
+        d = np.abs(got - exp)
+        assert (d > 1).mean() < 1e-4 and (d > 0).mean() < 1e-3, ((d > 1).sum(), (d > 0).sum())
+    a = gf.view(np.int32).astype(np.int64); b = ef.view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a); b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    d = np.abs(a - b)
+    assert (d > 1).mean() < 1e-4, (d > 1).sum()
+
+
+def test_forward_with_counter_sampler_shards_by_index(ofdg):
+    import torch
+    W, H, B = 128, 96, 4
+    outs = []
+    for rank in range(2):
+        g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=3, batch_size=B, rank=rank, world_size=2))
+        g.pool_synthetic(3, 256, 192, 1)
+        i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+        g.forward(i0, i1, fl); g.synchronize()      # step 0
+        a = i0.clone()
+        g.forward(i0, i1, fl); g.synchronize()      # step 1
+        outs.append((a, i0.clone()))
+    ref = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=3))
+    ref.pool_synthetic(3, 256, 192, 1)
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    for step in range(2):
+        for rank in range(2):
+            ref.forward_counter(step * B * 2 + rank * B, B, i0, i1, fl); ref.synchronize()
+            assert torch.equal(i0, outs[rank][step])

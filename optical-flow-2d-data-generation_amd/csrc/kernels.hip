@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
   const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
   if (sf >= (n_shapes_dev ? *n_shapes_dev : n_shapes) * 2) return;  // wave-uniform
   const DevShape& S = shapes[sf >> 1];
+  if (S.type == 0) return;  // unused slot of a device-sampled batch (wave-uniform)
   const Mat M = S.m[sf & 1];
   int2* out = verts + (size_t)sf * kMaxVerts;
 

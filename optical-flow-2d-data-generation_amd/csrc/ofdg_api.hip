@@ -73,8 +73,14 @@ struct ofdg_ctx {
     bool compose_pending = false;
     int* d_item_count = nullptr;
     int res_samples = 0, res_shapes = 0;
+    // counter sampler: records already sampled (ahead of time) for samples cs_index..cs_index+cs_n-1
+    long long cs_index = -1;
+    int cs_n = 0;
+    hipEvent_t ev_sampled = nullptr;
+    bool sampled_pending = false;
   };
-  static constexpr int kSlots = 16;
+  static constexpr int kUserSlots = 16;              // ofdg_upload_slot / ofdg_render_slot
+  static constexpr int kSlots = kUserSlots + 4;     // + the counter sampler's private ring
   Slot slots[kSlots];
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
@@ -84,8 +90,9 @@ struct ofdg_ctx {
   CsMode cs_mode;
   DevBuf<ofdg_blueprint> d_cs_bps;
   DevBuf<int> d_cs_nobj;
-  int* d_cs_nshapes = nullptr;
   long long next_index = 0;  // next global sample index of this rank's stream
+  hipStream_t cs_stream = nullptr;    // samples batch i+1 while batch i is prepared and batch i-1 composed
+  long long cs_calls = 0, cs_last_index = -1;
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
   float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
@@ -212,7 +219,8 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   // their stream the highest priority so that their workgroups are dispatched first
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if ((e = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
+  if ((e = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->cs_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
@@ -255,13 +263,14 @@ void ofdg_destroy(ofdg_ctx* c) {
   for (auto& sl : c->slots) {
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
     if (sl.ev_composed) (void)hipEventDestroy(sl.ev_composed);
+    if (sl.ev_sampled) (void)hipEventDestroy(sl.ev_sampled);
   }
   if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+  if (c->cs_stream) (void)hipStreamDestroy(c->cs_stream);
   if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
   if (c->d_warp) (void)hipFree(c->d_warp);
   if (c->d_warp_max) (void)hipFree(c->d_warp_max);
   c->d_cs_bps.release(); c->d_cs_nobj.release();
-  if (c->d_cs_nshapes) (void)hipFree(c->d_cs_nshapes);
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
@@ -360,6 +369,18 @@ int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps,
 }
 
 // ---- render -------------------------------------------------------------------------------
+// device counter sampler + device realize fill the slot's records (no host data)
+static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
+  const int stride = sl.res_shapes / sl.res_samples;
+  CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride};
+  hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples), dim3(256), 0, s, c->cs_mode, D, first_index, sl.d_shapes.p,
+                     sl.d_objects.p, sl.d_samples.p, c->d_err);
+  HIP_OK(c, hipGetLastError());
+  sl.cs_index = first_index;
+  sl.cs_n = sl.res_samples;
+  return OFDG_OK;
+}
+
 static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st,
                            long long cs_first_index = -1) {
   const int W = c->prm.width, H = c->prm.height;
@@ -391,15 +412,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
   const int* n_shapes_dev = nullptr;
   if (cs_first_index >= 0) {
-    // device counter sampler + device realize feed the slot's records (no host data)
-    hipLaunchKernelGGL(cs_sample_kernel, dim3(sl.res_samples), dim3(256), 0, ps, c->cs_mode, cs_first_index, sl.res_samples,
-                       c->d_cs_bps.p, c->d_cs_nobj.p);
-    HIP_OK(c, hipGetLastError());
-    CsRealizeDims D{W, H, c->pool_n, c->pool_w, c->pool_h, sl.res_samples};
-    hipLaunchKernelGGL(cs_realize_kernel, dim3(1), dim3(1024), 0, ps, D, c->d_cs_bps.p, c->d_cs_nobj.p, sl.d_shapes.p,
-                       sl.d_objects.p, sl.d_samples.p, c->d_cs_nshapes, sl.res_shapes, c->d_err);
-    HIP_OK(c, hipGetLastError());
-    n_shapes_dev = c->d_cs_nshapes;
+    if (sl.sampled_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_sampled, 0));
+    sl.sampled_pending = false;
+    if (sl.cs_index != cs_first_index || sl.cs_n != sl.res_samples) {
+      // not sampled ahead of time: device counter sampler + device realize now
+      int rc = launch_counter_sampler(c, sl, cs_first_index, ps);
+      if (rc != OFDG_OK) return rc;
+    }
+    sl.cs_index = -1;  // consumed
   }
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
@@ -586,7 +606,7 @@ int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blu
 
 int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
                      void* stream) {
-  if (!c || !tasks || !bps || n_tasks < 1 || slot < 0 || slot >= ofdg_ctx::kSlots) {
+  if (!c || !tasks || !bps || n_tasks < 1 || slot < 0 || slot >= ofdg_ctx::kUserSlots) {
     if (c) c->err = "ofdg_upload_slot: invalid argument";
     return OFDG_EINVAL;
   }
@@ -594,7 +614,7 @@ int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks,
 }
 
 int ofdg_render_slot(ofdg_ctx* c, int slot, float* d_img0, float* d_img1, float* d_flow, void* stream) {
-  if (!c || !d_img0 || !d_img1 || !d_flow || slot < 0 || slot >= ofdg_ctx::kSlots) return OFDG_EINVAL;
+  if (!c || !d_img0 || !d_img1 || !d_flow || slot < 0 || slot >= ofdg_ctx::kUserSlots) return OFDG_EINVAL;
   if (c->slots[slot].res_samples <= 0) { c->err = "ofdg_render_slot: no batch is resident in this slot"; return OFDG_EINVAL; }
   return launch_resident(c, c->slots[slot], d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
@@ -603,8 +623,8 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
   return ofdg_render_slot(c, 0, d_img0, d_img1, d_flow, stream);
 }
 
-// size slot `sl` for n device-sampled samples (upper bounds; the kernels read the actual
-// shape count from device memory)
+// size slot `sl` for n device-sampled samples: a fixed number of shape slots per sample
+// (unused ones are typed 0 and produce no outline)
 static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (c->prm.mode == 9) { c->err = "the counter sampler does not support mode 9 yet (use the ref sampler)"; return OFDG_EINVAL; }
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
@@ -612,10 +632,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   const int W = c->prm.width, H = c->prm.height;
   const size_t shapes_cap = (size_t)n * (c->prm.mode >= 6 ? 96 : kCsMaxObjects);
   const size_t n_obj = (size_t)n * (1 + kCsMaxObjects);
-  HIP_OK(c, c->d_cs_bps.reserve((size_t)n * kCsBlueprintsPerSample));
-  HIP_OK(c, c->d_cs_nobj.reserve(n));
-  if (!c->d_cs_nshapes) HIP_OK(c, hipMalloc((void**)&c->d_cs_nshapes, sizeof(int)));
-  HIP_OK(c, sl.d_shapes.reserve(shapes_cap + 8));  // (+ slack: a composite may overshoot the estimate, see below)
+  HIP_OK(c, sl.d_shapes.reserve(shapes_cap));
   HIP_OK(c, sl.d_frames.reserve(shapes_cap * 2));
   HIP_OK(c, sl.d_verts.reserve(shapes_cap * 2 * kMaxVerts));
   HIP_OK(c, sl.d_objects.reserve(n_obj));
@@ -639,7 +656,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
     HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
   }
   sl.res_samples = n;
-  sl.res_shapes = (int)shapes_cap;  // launch bound; the kernels use the device-side count
+  sl.res_shapes = (int)shapes_cap;
   sl.res_objects = (int)n_obj;
   sl.batch.samples.clear();
   return OFDG_OK;
@@ -650,11 +667,31 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
 int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
                          void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
-  // alternate between two slots so that consecutive launches overlap
-  ofdg_ctx::Slot& sl = c->slots[ofdg_ctx::kSlots - 1 - (int)(c->launch_count & 1)];
+  // A ring of four private slots.  After launching batch i the sampler is started for the
+  // batch the caller will most likely ask for next (same stride as last time) on its own
+  // stream, so that it overlaps geom/raster of batch i and compose of batch i-1; a wrong
+  // guess only costs the unused launch.
+  ofdg_ctx::Slot& sl = c->slots[ofdg_ctx::kUserSlots + (int)(c->cs_calls & 3)];
+  ofdg_ctx::Slot& nx = c->slots[ofdg_ctx::kUserSlots + (int)((c->cs_calls + 1) & 3)];
+  c->cs_calls++;
   int rc = prepare_counter_slot(c, sl, n_samples);
   if (rc != OFDG_OK) return rc;
-  return launch_resident(c, sl, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
+  rc = launch_resident(c, sl, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
+  if (rc != OFDG_OK) return rc;
+  const long long delta = c->cs_last_index >= 0 && first_index > c->cs_last_index ? first_index - c->cs_last_index : n_samples;
+  c->cs_last_index = first_index;
+  if (c->overlap) {
+    rc = prepare_counter_slot(c, nx, n_samples);
+    if (rc != OFDG_OK) return rc;
+    if (nx.sampled_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_sampled, 0));
+    if (nx.compose_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_composed, 0));
+    rc = launch_counter_sampler(c, nx, first_index + delta, c->cs_stream);
+    if (rc != OFDG_OK) return rc;
+    if (!nx.ev_sampled) HIP_OK(c, hipEventCreateWithFlags(&nx.ev_sampled, hipEventDisableTiming));
+    HIP_OK(c, hipEventRecord(nx.ev_sampled, c->cs_stream));
+    nx.sampled_pending = true;
+  }
+  return OFDG_OK;
 }
 
 // Download the blueprints the counter sampler produces for samples first_index.. (tests):

@@ -1,0 +1,19 @@
+"""Counter-sampler forward path timing (device sample+realize -> geom -> raster -> compose)."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+W, H, B = 512, 384, 32
+MODE = int(os.environ.get("MODE", "5")); NOBJ = int(os.environ.get("NOBJ", "16"))
+g = ofdg.Generator(ofdg.default_params(mode=MODE, batch_size=B, width=W, height=H, num_objects=NOBJ, sampler=1, seed=5))
+g.pool_synthetic(1000, 1024, 768, seed=1)
+i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+st = torch.cuda.current_stream().cuda_stream
+for i in range(20): g.forward_counter(i * B, B, i0, i1, fl, st)
+torch.cuda.synchronize()
+N = int(os.environ.get("N", "300"))
+t = time.perf_counter()
+for i in range(N): g.forward_counter((20 + i) * B, B, i0, i1, fl, st)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / N
+print(f"counter-sampler forward mode={MODE}: step={dt*1e6:.1f} us -> {B/dt:.0f} samples/s")

@@ -6,12 +6,19 @@
 
 Workload (BASELINE.json configs[1]): FlyingChairs mode 5, 512x384, batch 32 per GPU,
 16 objects, affine-only motion, AA on, synthetic 1000 x 1024x768 texture pool.
-A "step" is one pass of the hot path (geom -> raster -> compose kernels) over one batch
-of 32 blueprinted samples.  Inputs (realised blueprints, texture pool) are resident in
-HBM when the timed region starts; NSLOT distinct batches are rotated so that no step
-re-renders the batch it rendered last (their backgrounds together exceed the 256 MiB
-Infinity Cache).  Samples shard across ranks with no data-path collective ("weak"
-scaling): rank r renders block r of every B*world consecutive samples of the stream.
+A "step" is one pass of the whole hot path over one batch of 32 NEW samples:
+
+  --sampler counter (default): motion/shape sampling + realize (cs_sample_realize kernel,
+      Philox counter streams) -> geom -> raster -> compose, everything on the device; the
+      only input resident in HBM is the texture pool.  Every step renders samples never
+      rendered before (global indices step*B*world + rank*B + [0, B)).
+  --sampler resident: the reference's 45 mt19937 streams are sampled on the host before the
+      timed region; NSLOT realised batches are resident in HBM and rotated (their
+      backgrounds together exceed the 256 MiB Infinity Cache); a step is geom -> raster ->
+      compose.
+
+Samples shard across ranks with no data-path collective ("weak" scaling): rank r renders
+block r of every B*world consecutive samples of the stream.
 """
 import argparse
 import importlib
@@ -26,6 +33,7 @@ sys.path.insert(0, ROOT)
 W, H, MODE, BATCH, NOBJ = 512, 384, 5, 32, 16
 POOL_N, POOL_W, POOL_H, POOL_SEED = 1000, 1024, 768, 2024
 NSLOT = 12
+SEED = 20261003
 ALG_BYTES_PER_SAMPLE = 38 * W * H       # 32 B/px written (8 fp32 planes) + 6 B/px background read
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -64,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler", choices=("counter", "resident"), default="counter")
     args = ap.parse_args()
 
     import torch
@@ -75,38 +84,44 @@ def main():
     torch.cuda.set_device(local_rank)
     ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
 
-    header = torch.tensor([MODE, W, H, NOBJ, POOL_N, POOL_W, POOL_H, POOL_SEED], dtype=torch.int64, device="cuda")
+    header = torch.tensor([MODE, W, H, NOBJ, POOL_N, POOL_W, POOL_H, POOL_SEED, SEED], dtype=torch.int64, device="cuda")
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl")
-        # the one collective of this path: rank 0's stream/pool description, over RCCL
+        # the one collective of this path: rank 0's seed + stream/pool description, over RCCL
         if rank != 0:
             header.zero_()
         dist.broadcast(header, src=0)
-    mode, w, h, nobj, pool_n, pool_w, pool_h, pool_seed = [int(v) for v in header.tolist()]
+    mode, w, h, nobj, pool_n, pool_w, pool_h, pool_seed, seed = [int(v) for v in header.tolist()]
 
+    counter = args.sampler == "counter"
     prm = ofdg.default_params(width=w, height=h, mode=mode, num_objects=nobj, batch_size=BATCH,
-                              rank=rank, world_size=world, device=local_rank)
+                              rank=rank, world_size=world, device=local_rank, sampler=1 if counter else 0, seed=seed)
     gen = ofdg.Generator(prm)
     gen.pool_synthetic(pool_n, pool_w, pool_h, pool_seed)
-
-    # every rank walks the same reference stream and keeps its own block of each B*world tasks
-    sampler = ofdg.HostSampler(mode, w, h, nobj)
     stream = torch.cuda.current_stream().cuda_stream
-    first = None
-    t_s = time.perf_counter()
-    for slot in range(NSLOT):
-        tasks, bps, n_bps = sampler.next(BATCH * world, cap=BATCH * world * 64)
-        mine = (ofdg.Task * BATCH)(*[tasks[rank * BATCH + i] for i in range(BATCH)])
-        gen.upload_slot(slot, mine, BATCH, bps, n_bps, stream)
-        if first is None:
-            first = (mine, bps, n_bps)
-    host_sampler_rate = NSLOT * BATCH * world / (time.perf_counter() - t_s)
     img0, img1, flow = ofdg.alloc_outputs(BATCH, h, w)
+
+    host_sampler_rate = None
+    if counter:
+        def step(i):
+            gen.forward(img0, img1, flow, stream)  # samples (step*world + rank)*B + [0, B) on the device, then renders
+    else:
+        # every rank walks the same reference stream and keeps its own block of each B*world tasks
+        sampler = ofdg.HostSampler(mode, w, h, nobj)
+        t_s = time.perf_counter()
+        for slot in range(NSLOT):
+            tasks, bps, n_bps = sampler.next(BATCH * world, cap=BATCH * world * 64)
+            mine = (ofdg.Task * BATCH)(*[tasks[rank * BATCH + i] for i in range(BATCH)])
+            gen.upload_slot(slot, mine, BATCH, bps, n_bps, stream)
+        host_sampler_rate = NSLOT * BATCH * world / (time.perf_counter() - t_s)
+
+        def step(i):
+            gen.render_slot(i % NSLOT, img0, img1, flow, stream)
     gen.synchronize(stream)
 
     for i in range(args.warmup):
-        gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+        step(i)
     gen.synchronize(stream)
     gen.set_profiling(1)  # HIP events around the compose kernel, on the launch stream
 
@@ -119,7 +134,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+        step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
@@ -135,7 +150,7 @@ def main():
         # second short pass with all three kernels timed (not part of `value`)
         gen.set_profiling(2)
         for i in range(min(args.steps, 48)):
-            gen.render_slot(i % NSLOT, img0, img1, flow, stream)
+            step(i)
         gen.synchronize(stream)
         parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
         gen.set_profiling(0)
@@ -153,15 +168,19 @@ def main():
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
             "config": {"workload": "FlyingChairs mode 5, 512x384, batch=32 per GPU, 16 objects, affine-only motion, "
                                    "AA on, synthetic 1000x(1024x768) texture pool (BASELINE configs[1])",
-                       "batch_per_gpu": BATCH, "resident_batches": NSLOT, "sampler": "ref (host), outside the timed region"},
+                       "batch_per_gpu": BATCH,
+                       "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
+                                   if counter else
+                                   "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "compose_kernel", "kernel_ms": compose_ms,
                          "algorithmic_bytes_per_launch": BATCH * ALG_BYTES_PER_SAMPLE},
             "kernel_ms": parts,
             "hbm_gbs_whole_step": value / world * ALG_BYTES_PER_SAMPLE / 1e9,
-            "host_ref_sampler_samples_per_s": host_sampler_rate,
         }
+        if host_sampler_rate is not None:
+            out["host_ref_sampler_samples_per_s"] = host_sampler_rate
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ofdg, gen)
         print(json.dumps(out))

@@ -73,7 +73,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // --------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 16, kPx = 4;
 constexpr int kChunkW = 128;  // columns one raster item covers
-constexpr int kGeomWaves = 4;
+constexpr int kGeomWaves = 1;   // single-wave workgroups: any retiring compose wave makes room for one
 constexpr int kCurveSlots = 10;  // a polygon of <= 20 segments holds <= 9 curve3 segments
 
 // curve3_div::recursive_bezier as an explicit depth-first walk (left subtree first).
@@ -138,14 +138,14 @@ __device__ __forceinline__ int flatten_curve3(double x1, double y1, double x2, d
   return cnt;
 }
 
-// Object boxes are stored as {x0, y0, -x1, -y1} so that one atomicMin grows them and
-// one byte pattern (0x7F) empties them.
-constexpr int kEmptyBox = 0x7F7F7F7F;
+// Block masks: for every 64 x 8 block of every sample two 64-bit words (frame 0, frame 1);
+// bit k = the (dilated) box of an outline of foreground object k touches the block.  compose
+// reads its block's pair with one scalar load and visits exactly these objects.
 
-__global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
+__global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
                                                    const double* __restrict__ cs_tab, int W, int H,
                                                    DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
-                                                   int4* __restrict__ obj_box, uint32_t* __restrict__ err,
+                                                   unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
                                                    int* __restrict__ item_count, int4* __restrict__ items,
                                                    const DevCropRef* __restrict__ crops,
                                                    const int* __restrict__ n_shapes_dev) {
@@ -250,16 +250,20 @@ __global__ __launch_bounds__(256) void geom_kernel(const DevShape* __restrict__ 
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
     f.pad[0] = f.pad[1] = f.pad[2] = 0;
     frames[sf] = f;
-    if (visible) {
-      int* box = reinterpret_cast<int*>(&obj_box[S.object * 2 + (sf & 1)]);  // union over the object's outlines, per frame
-      atomicMin(box + 0, bx0); atomicMin(box + 1, by0); atomicMin(box + 2, -bx1); atomicMin(box + 3, -by1);
-    }
   }
   // Raster work list: one item per 8-row band x 128-column chunk of the 64 x 8 blocks the
   // (dilated) box touches.  Coverage outside these blocks is never read: compose tests the
   // block against the same box.
   if (visible) {
     const int band0 = by0 / kBandRows, band1 = by1 / kBandRows;
+    {  // mark the blocks for compose
+      const int nbx = (W + kTileW - 1) / kTileW, nby = (H + kBandRows - 1) / kBandRows;
+      const int c0 = bx0 / kTileW, nc = bx1 / kTileW - c0 + 1;
+      unsigned long long* m = blockmask + ((size_t)S.sample * nbx * nby) * 2 + (sf & 1);
+      const unsigned long long bit = 1ull << S.obj_local;
+      for (int i = lane; i < (band1 - band0 + 1) * nc; i += 64)
+        atomicOr(m + (size_t)((band0 + i / nc) * nbx + c0 + i % nc) * 2, bit);
+    }
     const int xa = (bx0 / kTileW) * kTileW, xb = min((bx1 / kTileW) * kTileW + kTileW - 1, W - 1);
     const int nchunks = (xb - xa + kChunkW) / kChunkW;
     const int n_items = (band1 - band0 + 1) * nchunks;
@@ -497,7 +501,7 @@ struct ChunkAcc {
   }
 };
 
-constexpr int kRasterWaves = 4;
+constexpr int kRasterWaves = 1;
 struct ChunkCells {
   int cover[kBandRows][kChunkW];
   int area[kBandRows][kChunkW];
@@ -506,20 +510,17 @@ struct ChunkCells {
 
 // One WAVE per item (no workgroup barriers): clear its cells, accumulate every
 // (edge, scanline) pair of the outline that can reach the chunk, sweep, store.
-__global__ __launch_bounds__(256) void raster_kernel(const DevShapeFrame* __restrict__ frames,
+__global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShapeFrame* __restrict__ frames,
                                                      const int4* __restrict__ items,
                                                      const int* __restrict__ item_count,
                                                      const int2* __restrict__ verts, int W, int H,
-                                                     uint8_t* __restrict__ cov, int4* __restrict__ obj_box,
-                                                     int n_objects) {
+                                                     uint8_t* __restrict__ cov,
+                                                     unsigned long long* __restrict__ blockmask_next, int n_mask_words) {
   __shared__ __attribute__((aligned(16))) ChunkCells s_cells[kRasterWaves];
   __shared__ int s_queue[kRasterWaves][64 * kBandRows];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // empty the object boxes the NEXT launch of this slot accumulates into (the other parity)
-  {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < n_objects * 2) obj_box[gid] = make_int4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
-  }
+  // clear the block masks the NEXT launch of this slot accumulates into (the other parity)
+  for (int gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_mask_words; gid += gridDim.x * blockDim.x) blockmask_next[gid] = 0ull;
   ChunkCells& tc = s_cells[wave];
   const int n_items = *item_count;
   const int n_waves = gridDim.x * kRasterWaves;
@@ -769,56 +770,39 @@ __device__ __forceinline__ int lerp_u8(const Taps& t, float Icc, float Inc, floa
 // Body of the compose kernel; kDeform adds the mode-9 paths (masks, textures and flow
 // re-sampled through per-object warp crops).
 template <bool kDeform>
-__device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
+__device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSample* __restrict__ samples,
                                              const DevObject* __restrict__ objects,
-                                             const int4* __restrict__ obj_box,
+                                             const unsigned long long* __restrict__ blockmask,
                                              const uint8_t* __restrict__ cov,
                                              const uint32_t* __restrict__ pool,
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  // raster_kernel has consumed the work list: reset the counter for this slot's next launch
-  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
-  // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give
-  // every XCD a contiguous run of tiles (whole samples): their background rows,
-  // coverage slots and object records then stay in that XCD's L2.
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7, slot = bid >> 3;
-    bid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + slot;
-  }
+                                             const DevCropRef* __restrict__ crops, int bid, int tid) {
   const int tiles = dm.tiles_x * dm.tiles_y;
   const int s = bid / tiles;
   if (s >= dm.n_samples) return;
   const int t = bid - s * tiles;
   const int ty0 = (t / dm.tiles_x) * kTileH, tx0 = (t % dm.tiles_x) * kTileW;
   const int W = dm.W, H = dm.H;
-  const int x0 = tx0 + (threadIdx.x & 15) * kPx;
-  const int y = ty0 + (threadIdx.x >> 4);
+  const int x0 = tx0 + (tid & 15) * kPx;
+  const int y = ty0 + (tid >> 4);
   const bool inside = (x0 < W) && (y < H);  // W % 4 == 0 is required by the host
 
   const DevSample smp = samples[s];
   const DevObject* objs = objects + smp.first_object;
   // Every wave covers 4 rows: waves 0,1 the upper 64 x 8 block of the tile, waves 2,3 the
-  // lower.  Which objects can touch the block: lane l tests object l's per-frame box
-  // (accumulated by geom_kernel) and a ballot turns the answers into the bit masks.
+  // lower.  Which objects can touch the block: the block's mask pair (geom_kernel), one
+  // scalar load that depends on nothing but the block index.
   unsigned long long mask0, mask1;
   {
-    const int by0 = __builtin_amdgcn_readfirstlane(ty0 + (int)(threadIdx.x >> 7) * kBandRows);
-    const int lane = threadIdx.x & 63;
-    bool t0 = false, t1 = false;
-    if (lane + 1 < smp.n_objects) {
-      const int4* bx = obj_box + (size_t)(smp.first_object + 1 + lane) * 2;
-      const int4 b0 = bx[0], b1 = bx[1];  // {x0, y0, -x1, -y1}; empty: x0 > x1
-      t0 = b0.x <= tx0 + kTileW - 1 && -b0.z >= tx0 && b0.y <= by0 + kBandRows - 1 && -b0.w >= by0 && b0.x <= -b0.z;
-      t1 = b1.x <= tx0 + kTileW - 1 && -b1.z >= tx0 && b1.y <= by0 + kBandRows - 1 && -b1.w >= by0 && b1.x <= -b1.z;
-    }
-    mask0 = __ballot(t0);
-    mask1 = __ballot(t1);
+    const int nbx = dm.tiles_x, nby = (H + kBandRows - 1) / kBandRows;
+    const int brow = __builtin_amdgcn_readfirstlane((ty0 + (tid >> 7) * kBandRows) / kBandRows);
+    const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(blockmask + ((size_t)(s * nby + min(brow, nby - 1)) * nbx + tx0 / kTileW) * 2);
+    mask0 = mm.x; mask1 = mm.y;
   }
   unsigned long long omask = mask0 | mask1;
+  if (dm.dbg & 1) omask = 0;
 
   const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
   const size_t slot_bytes = (size_t)W * H;
@@ -836,7 +820,10 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
     g.nshift = ((g.tw & (g.tw - 1)) == 0) ? (31 - __clz(g.tw)) : -1;
     g.pitch = dm.pool_w;
     const int yy = y + H / 2, xx = x0 + W / 2;
-    if (inside) {
+    if (dm.dbg & 16) {
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) { px0[p] = 0x123456u + p; px1[p] = 0x654321u + x0; fu[p] = 1.f; fv[p] = 2.f; }
+    } else if (inside) {
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
       const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
       const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
@@ -955,7 +942,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
     if (O.kind == 1) {
       const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
       uint32_t c0w = 0, c1w = 0;
-      if (inside) {
+      if (inside && !(dm.dbg & 8)) {
         if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
         if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
       }
@@ -987,7 +974,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
         uint32_t c0w = 0, c1w = 0;
         if (inside) {
           // a component's coverage exists only in the 64 x 8 blocks its own box touches
-          const int by0c = ty0 + (int)(threadIdx.x >> 7) * kBandRows;
+          const int by0c = ty0 + (tid >> 7) * kBandRows;
           const DevShapeFrame F0 = frames[(O.first_shape + k) * 2], F1 = frames[(O.first_shape + k) * 2 + 1];
           int d1 = 0;
           if constexpr (kDeform) { if (O.deform > 0) d1 = (int)ceilf(__uint_as_float(*crops[O.deform - 1].max_bits)) + 2; }
@@ -1027,7 +1014,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
     const int any1 = m1[0] | m1[1] | m1[2] | m1[3];
     const int anyn = na0[0] | na0[1] | na0[2] | na0[3];
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
-    if (any0) {  // frame 0 texture: identity warp == the crop itself (DG:339-340)
+    if (any0 && !(dm.dbg & 4)) {  // frame 0 texture: identity warp == the crop itself (DG:339-340)
       const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
       const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
@@ -1036,7 +1023,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
     uint32_t t1[kPx] = {0, 0, 0, 0};
     bool deform_tex = false;
     if constexpr (kDeform) deform_tex = (O.deform > 0);
-    if (any1 && !deform_tex) {
+    if (any1 && !deform_tex && !(dm.dbg & 2)) {
       const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) t1[p] = sample_bilinear(tex, g, R, x0 + p);
@@ -1103,6 +1090,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   }
 
   if (!inside) return;
+  if ((dm.dbg & 32) && px0[0] != 0xFFFFFFFFu) return;
   // u8 -> float planes (DG:1229-1245); streaming 16-byte stores, never re-read
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const size_t plane = (size_t)W * H;
@@ -1122,20 +1110,46 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
 }
 
-__global__ __launch_bounds__(256) void compose_kernel(
+template <bool kDeform>
+__device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
+                                             const DevObject* __restrict__ objects,
+                                             const unsigned long long* __restrict__ blockmask,
+                                             const uint8_t* __restrict__ cov,
+                                             const uint32_t* __restrict__ pool,
+                                             float* __restrict__ img0, float* __restrict__ img1,
+                                             float* __restrict__ flow,
+                                             const DevShapeFrame* __restrict__ frames,
+                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  // raster_kernel has consumed the work list: reset the counter for this slot's next launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
+  // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give
+  // every XCD a contiguous run of tiles (whole samples): their background rows,
+  // coverage slots and object records then stay in that XCD's L2.
+  const int nblk = gridDim.x;
+  int wg = blockIdx.x;
+  {
+    const int q = nblk >> 3, rm = nblk & 7, xcd = wg & 7, slot = wg >> 3;
+    wg = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + slot;
+  }
+  // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
+  // of four sibling waves retires
+  compose_tile<kDeform>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void compose_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const int4* __restrict__ obj_box, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_body<false>(dm, samples, objects, obj_box, cov, pool, img0, img1, flow, frames, nullptr, item_count);
+  compose_body<false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
 }
 // Mode 9: the same kernel with the deformation paths compiled in.
-__global__ __launch_bounds__(256) void compose_deform_kernel(
+__global__ __launch_bounds__(64) void compose_deform_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const int4* __restrict__ obj_box, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  compose_body<true>(dm, samples, objects, obj_box, cov, pool, img0, img1, flow, frames, crops, item_count);
+  compose_body<true>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, item_count);
 }
 
 // --------------------------------------------------------------------------

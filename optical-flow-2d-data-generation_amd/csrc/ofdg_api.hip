@@ -60,10 +60,11 @@ struct ofdg_ctx {
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
     DevBuf<int4> d_items;
-    DevBuf<int4> d_obj_box;  // [2 parities][objects][2 frames]
+    DevBuf<unsigned long long> d_blockmask;  // [2 parities][samples][64 x 8 blocks][2 frames]
     int res_objects = 0;
     int box_parity = 0;
-    size_t box_stride = 0;   // int4 elements per parity
+    size_t box_stride = 0;   // mask words per parity
+    int mask_used[2] = {0, 0};  // words the last launch on each parity marked (what the next clear must cover)
     hipEvent_t ev_uploaded = nullptr;
     bool upload_pending = false;
     DevBuf<DevCropRef> d_croptab;      // mode 9: crops of this batch's deforming objects
@@ -251,7 +252,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
-    sl.d_items.release(); sl.d_obj_box.release();
+    sl.d_items.release(); sl.d_blockmask.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
@@ -368,6 +369,21 @@ int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps,
   return OFDG_OK;
 }
 
+// block masks of a slot: two parities, cleared once here; afterwards raster_kernel clears
+// the other parity every launch
+static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
+  const int W = c->prm.width, H = c->prm.height;
+  const size_t words = (size_t)n_samples * ((W + kTileW - 1) / kTileW) * ((H + kBandRows - 1) / kBandRows) * 2;
+  if (words > sl.box_stride) {
+    HIP_OK(c, hipDeviceSynchronize());
+    HIP_OK(c, sl.d_blockmask.reserve((words + 16) * 2));
+    sl.box_stride = sl.d_blockmask.cap / 2;
+    HIP_OK(c, hipMemset(sl.d_blockmask.p, 0, sl.d_blockmask.cap * sizeof(unsigned long long)));
+    sl.mask_used[0] = sl.mask_used[1] = 0;
+  }
+  return OFDG_OK;
+}
+
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
@@ -392,6 +408,8 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
+  { static const int dbg = getenv("OFDG_DBG") ? atoi(getenv("OFDG_DBG")) : 0; dm.dbg = dbg; }
+  const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
     ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
@@ -424,17 +442,19 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
   sl.box_parity ^= 1;
-  int4* box_cur = sl.d_obj_box.p + (size_t)bp * sl.box_stride;
-  int4* box_next = sl.d_obj_box.p + (size_t)(bp ^ 1) * sl.box_stride;
-  hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(256), 0, ps, sl.d_shapes.p,
+  unsigned long long* box_cur = sl.d_blockmask.p + (size_t)bp * sl.box_stride;
+  unsigned long long* box_next = sl.d_blockmask.p + (size_t)(bp ^ 1) * sl.box_stride;
+  sl.mask_used[bp] = sl.res_samples * dm.tiles_x * ((H + kBandRows - 1) / kBandRows) * 2;
+  const int n_mask_words = sl.mask_used[bp ^ 1];
+  hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps, sl.d_shapes.p,
                      sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count,
                      sl.d_items.p, sl.d_croptab.p, n_shapes_dev);
   HIP_OK(c, hipGetLastError());
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
-    hipLaunchKernelGGL(raster_kernel, dim3(rgrid), dim3(256), 0, ps, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
-                       sl.d_verts.p, W, H, cov, box_next, sl.res_objects);
+    hipLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
+                       sl.d_verts.p, W, H, cov, box_next, n_mask_words);
     HIP_OK(c, hipGetLastError());
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[2], ps));
@@ -444,14 +464,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   }
   if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
   if (c->prm.mode == 9)
-    hipLaunchKernelGGL(compose_deform_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm,
+    hipLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, dm,
                        sl.d_samples.p, sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow,
                        sl.d_frames.p, sl.d_croptab.p, sl.d_item_count);
   else
     // compose_kernel allocates 104 VGPRs -> 4 waves per SIMD; the remaining 96 registers per
     // lane and all of the LDS are what lets the latency-bound preparation kernels of the
     // next batch (internal stream) co-reside with it.
-    hipLaunchKernelGGL(compose_kernel, dim3(dm.tiles_x * dm.tiles_y * dm.n_samples), dim3(256), 0, st, dm, sl.d_samples.p,
+    hipLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, dm, sl.d_samples.p,
                        sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
@@ -491,14 +511,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
     (void)tiles;
     HIP_OK(c, sl.d_items.reserve(n_shapes * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
-    if (n_obj * 2 > sl.box_stride) {
-      HIP_OK(c, hipDeviceSynchronize());
-      sl.box_stride = n_obj * 2 + n_obj / 2 + 16;
-      HIP_OK(c, sl.d_obj_box.reserve(sl.box_stride * 2));
-      sl.box_stride = sl.d_obj_box.cap / 2;
-      // emptied once here; afterwards raster_kernel re-empties the other parity every launch
-      HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
-    }
+    { int rcm = reserve_blockmask(c, sl, n_tasks); if (rcm != OFDG_OK) return rcm; }
     if (!sl.d_item_count) {
       HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
       HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
@@ -644,13 +657,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
     HIP_OK(c, c->d_cov2[1].reserve(need_cov));
   }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
-  if (n_obj * 2 > sl.box_stride) {
-    HIP_OK(c, hipDeviceSynchronize());
-    sl.box_stride = n_obj * 2 + 16;
-    HIP_OK(c, sl.d_obj_box.reserve(sl.box_stride * 2));
-    sl.box_stride = sl.d_obj_box.cap / 2;
-    HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
-  }
+  { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
   if (!sl.d_item_count) {
     HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
     HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
@@ -897,16 +904,11 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
     for (int cx = 0; cx < W; cx += kChunkW) items.push_back(make_int4(0, b, cx, std::min(cx + kChunkW - 1, W - 1)));
   const int n_items = (int)items.size();
   HIP_OK(c, sl.d_items.reserve(items.size()));
-  if (sl.d_obj_box.cap == 0) {
-    HIP_OK(c, sl.d_obj_box.reserve(32));
-    sl.box_stride = sl.d_obj_box.cap / 2;
-    HIP_OK(c, hipMemset(sl.d_obj_box.p, 0x7F, sl.d_obj_box.cap * sizeof(int4)));
-  }
   if (!sl.d_item_count) HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
   HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(raster_kernel, dim3(64), dim3(256), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
-                     W, H, c->d_cov2[0].p, sl.d_obj_box.p, 0);
+  hipLaunchKernelGGL(raster_kernel, dim3(64 * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
+                     W, H, c->d_cov2[0].p, nullptr, 0);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipMemcpy(coverage_host, c->d_cov2[0].p, (size_t)W * H, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));

@@ -38,7 +38,7 @@ struct DevShape {
   int32_t sample;  // batch slot
   int32_t deform;  // mode 9: frame-1 mask is re-sampled through warp slot `deform-1`
   int32_t object;  // index of the owning DevObject in the batch
-  int32_t pad;
+  int32_t obj_local;  // index of the owner among its sample's foreground objects (bit of the block masks)
 };
 
 // Produced by the geom kernel for each (shape, frame).
@@ -84,6 +84,7 @@ struct RenderDims {
   int32_t n_samples;
   int32_t n_shapes;        // total rasterised shapes in the batch
   int32_t tiles_x, tiles_y;
+  int32_t dbg;
 };
 
 }  // namespace ofdg

@@ -24,7 +24,7 @@ Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H
   return r;
 }
 
-int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object, int deform,
+int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object, int obj_local, int deform,
                std::vector<DevShape>* shapes, std::string* msg) {
   if (p.obj_type != OFDG_OBJ_ELLIPSE && p.obj_type != OFDG_OBJ_POLYGON) {
     *msg = "(RealizeObjectBlueprint) Bad object type, or not intended in this mode";  // DataGenerator.cpp:1143
@@ -39,6 +39,7 @@ int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_
   s.ry = p.ellipse_scale_y;
   s.sample = sample;
   s.object = object;
+  s.obj_local = obj_local;
   s.deform = deform;
   if (p.obj_type == OFDG_OBJ_POLYGON) {
     if (p.n_segments < 1 || p.n_segments > kMaxSegments) {
@@ -160,7 +161,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         for (int k = 0; k < p.n_components; ++k) {
           const ofdg_blueprint& c = bps[p.first_component + k];
           const int cdef = (mode9 && c.do_warpfield_deformation) ? o.deform : 0;
-          int rc = push_shape(cfg, c, bg_motion, t, (int)out->objects.size(), cdef, &out->shapes, msg);
+          int rc = push_shape(cfg, c, bg_motion, t, (int)out->objects.size(), (int)out->objects.size() - smp.first_object - 1, cdef, &out->shapes, msg);
           if (rc != OFDG_OK) return rc;
           if (c.is_additive_component) o.additive |= (1u << k);
         }
@@ -168,7 +169,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         o.kind = 1;
         o.n_shapes = 1;
         if (mode9 && p.do_warpfield_deformation) o.deform = serve(false);  // DataGenerator.cpp:1164-1168
-        int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), o.deform, &out->shapes, msg);
+        int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), (int)out->objects.size() - smp.first_object - 1, o.deform, &out->shapes, msg);
         if (rc != OFDG_OK) return rc;
       }
       out->objects.push_back(o);

@@ -728,6 +728,63 @@ __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__
   return out;
 }
 
+// The same filter for kPx consecutive pixels of one row.  kPow2 (the row length is a power of
+// two, e.g. 512 or 1024): the interpolators advance by additions, and when every needed lane
+// of the wave stays inside the texture (no reflection: checked at the two end pixels, the
+// interpolators are monotone) the four taps of a pixel are two 8-byte loads.  Otherwise, and
+// for other row lengths, sample_bilinear.
+__device__ __forceinline__ uint32_t bilerp_rgb(uint2 t0, uint2 t1, uint32_t xf, uint32_t yf) {
+  // sum w_ij * p_ij with w = (256 - xf | xf) * (256 - yf | yf): vertical pass on 16-bit lanes
+  // (B and R share a multiply: (256 - yf) * a + yf * b <= 65280), horizontal pass per channel
+  const uint32_t ify = 256u - yf, ifx = 256u - xf;
+  const uint32_t rb0 = (t0.x & 0x00FF00FFu) * ify + (t1.x & 0x00FF00FFu) * yf;
+  const uint32_t rb1 = (t0.y & 0x00FF00FFu) * ify + (t1.y & 0x00FF00FFu) * yf;
+  const uint32_t g0 = ((t0.x >> 8) & 255u) * ify + ((t1.x >> 8) & 255u) * yf;
+  const uint32_t g1 = ((t0.y >> 8) & 255u) * ify + ((t1.y >> 8) & 255u) * yf;
+  const uint32_t b = (rb0 & 0xFFFFu) * ifx + (rb1 & 0xFFFFu) * xf + 32768u;
+  const uint32_t r = (rb0 >> 16) * ifx + (rb1 >> 16) * xf + 32768u;
+  const uint32_t g = g0 * ifx + g1 * xf + 32768u;
+  return (b >> 16) | ((g >> 8) & 0xFF00u) | (r & 0xFF0000u);
+}
+template <bool kPow2>
+__device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const WarpGeom& g, const RowDDA& R, int i0,
+                                        bool need, uint32_t out[kPx]) {
+  if constexpr (!kPow2) {
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear(tex, g, R, i0 + p);
+  } else {
+    int xh[kPx], yh[kPx];
+    {
+      int ax = (i0 + 1) * R.rx + g.tw - 1, bx = R.x1 - 129 + i0 * R.lx;  // dda_at(...) - 128
+      int ay = (i0 + 1) * R.ry + g.tw - 1, by = R.y1 - 129 + i0 * R.ly;
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        xh[p] = bx + (ax >> g.nshift); yh[p] = by + (ay >> g.nshift);
+        ax += R.rx; bx += R.lx; ay += R.ry; by += R.ly;
+      }
+    }
+    const bool in_range = (unsigned)(xh[0] >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(xh[kPx - 1] >> 8) <= (unsigned)(g.tw - 2) &&
+                          (unsigned)(yh[0] >> 8) <= (unsigned)(g.th - 2) && (unsigned)(yh[kPx - 1] >> 8) <= (unsigned)(g.th - 2);
+    if (__ballot(need && !in_range) == 0ull) {
+      const char* base = reinterpret_cast<const char*>(tex);
+      const uint32_t pitch4 = (uint32_t)g.pitch * 4u;
+      uint2 t0[kPx], t1[kPx];
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        // (lanes that do not need the result may point anywhere: clamp them to texel 0)
+        const uint32_t off = need ? ((uint32_t)(yh[p] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[p] >> 8)) * 4u : 0u;
+        t0[p] = *reinterpret_cast<const uint2*>(base + off);
+        t1[p] = *reinterpret_cast<const uint2*>(base + off + pitch4);
+      }
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) out[p] = bilerp_rgb(t0[p], t1[p], (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
+    } else {
+#pragma unroll 1
+      for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear(tex, g, R, i0 + p);
+    }
+  }
+}
+
 // One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a 64 x 16
 // tile.  Objects are visited in painter's order (ascending ID) through the tile's object
 // bit mask; their coverage comes from the slots raster_kernel filled (valid over every
@@ -769,7 +826,7 @@ __device__ __forceinline__ int lerp_u8(const Taps& t, float Icc, float Inc, floa
 
 // Body of the compose kernel; kDeform adds the mode-9 paths (masks, textures and flow
 // re-sampled through per-object warp crops).
-template <bool kDeform>
+template <bool kDeform, bool kPow2>
 __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSample* __restrict__ samples,
                                              const DevObject* __restrict__ objects,
                                              const unsigned long long* __restrict__ blockmask,
@@ -779,6 +836,9 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
                                              const DevCropRef* __restrict__ crops, int bid, int tid) {
+  if (dm.dbg & 256) return;
+  const unsigned long long t_start = (dm.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = (dm.dbg & 128) ? wall_clock64() : 0ull;
   const int tiles = dm.tiles_x * dm.tiles_y;
   const int s = bid / tiles;
   if (s >= dm.n_samples) return;
@@ -830,10 +890,10 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       const RowDDA R = make_row(B.tex_inv, yy, g.tw, g.nshift);
       // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
       const double by = (double)(y + H / 2) + (double)(-H);
+      sample4<kPow2>(tex, g, R, xx, true, px1);
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         px0[p] = tt[p] & 0x00FFFFFFu;
-        px1[p] = sample_bilinear(tex, g, R, xx + p);
         double ix = (double)(x0 + p + W / 2), iy = by;
         const float save_x = (float)(x0 + p + W / 2), save_y = (float)(y + H / 2);
         ix = ix + (double)(-W);
@@ -1025,8 +1085,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     if constexpr (kDeform) deform_tex = (O.deform > 0);
     if (any1 && !deform_tex && !(dm.dbg & 2)) {
       const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) t1[p] = sample_bilinear(tex, g, R, x0 + p);
+      sample4<kPow2>(tex, g, R, x0, true, t1);
     }
     if constexpr (kDeform) {
       if (any1 && deform_tex) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
@@ -1091,10 +1150,27 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
 
   if (!inside) return;
   if ((dm.dbg & 32) && px0[0] != 0xFFFFFFFFu) return;
+  const unsigned long long t_mid = (dm.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
   // u8 -> float planes (DG:1229-1245); streaming 16-byte stores, never re-read
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const size_t plane = (size_t)W * H;
   const size_t o = (size_t)y * W + x0;
+  if (dm.dbg & 64) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
+                 (float)((px0[2] >> (8 * c)) & 255u), (float)((px0[3] >> (8 * c)) & 255u)};
+      f32x4 b = {(float)((px1[0] >> (8 * c)) & 255u), (float)((px1[1] >> (8 * c)) & 255u),
+                 (float)((px1[2] >> (8 * c)) & 255u), (float)((px1[3] >> (8 * c)) & 255u)};
+      *reinterpret_cast<f32x4*>(img0 + ((size_t)s * 3 + c) * plane + o) = a;
+      *reinterpret_cast<f32x4*>(img1 + ((size_t)s * 3 + c) * plane + o) = b;
+    }
+    f32x4 u = {fu[0], fu[1], fu[2], fu[3]};
+    f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
+    *reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o) = u;
+    *reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o) = v;
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
@@ -1108,9 +1184,17 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
   f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
   __builtin_nontemporal_store(u, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o));
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
+  if (dm.dbg & 128) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if ((tid & 63) == 0) {
+      dm.dbg_buf[(size_t)(bid * 4 + (tid >> 6)) * 2 + 0] = t_mid - t_start;
+      dm.dbg_buf[(size_t)(bid * 4 + (tid >> 6)) * 2 + 1] = (t_end - t_mid) | ((wall_clock64() - r_start) << 32);
+    }
+  }
 }
 
-template <bool kDeform>
+template <bool kDeform, bool kPow2>
 __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
                                              const DevObject* __restrict__ objects,
                                              const unsigned long long* __restrict__ blockmask,
@@ -1133,7 +1217,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   }
   // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
   // of four sibling waves retires
-  compose_tile<kDeform>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
+  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void compose_kernel(
@@ -1141,7 +1225,15 @@ __global__ __launch_bounds__(64) void compose_kernel(
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_body<false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
+  compose_body<false, false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
+}
+// W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads.
+__global__ __launch_bounds__(64) void compose_pow2_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+  compose_body<false, true>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
 }
 // Mode 9: the same kernel with the deformation paths compiled in.
 __global__ __launch_bounds__(64) void compose_deform_kernel(
@@ -1149,7 +1241,7 @@ __global__ __launch_bounds__(64) void compose_deform_kernel(
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  compose_body<true>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, item_count);
+  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, item_count);
 }
 
 // --------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libofdg.so")
+LIB_PATH = os.environ.get("OFDG_LIB") or os.path.join(HERE, "lib", "libofdg.so")  # OFDG_LIB: A/B-test another build
 MAX_SEG = 20
 
 OK, EBADMODE, ETEXTURES, EOBJTYPE, EHIP, ECAPACITY, EINVAL = 0, -1, -2, -3, -4, -5, -6

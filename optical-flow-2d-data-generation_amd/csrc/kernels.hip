@@ -836,9 +836,6 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
                                              const DevCropRef* __restrict__ crops, int bid, int tid) {
-  if (dm.dbg & 256) return;
-  const unsigned long long t_start = (dm.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
-  const unsigned long long r_start = (dm.dbg & 128) ? wall_clock64() : 0ull;
   const int tiles = dm.tiles_x * dm.tiles_y;
   const int s = bid / tiles;
   if (s >= dm.n_samples) return;
@@ -862,7 +859,6 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     mask0 = mm.x; mask1 = mm.y;
   }
   unsigned long long omask = mask0 | mask1;
-  if (dm.dbg & 1) omask = 0;
 
   const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
   const size_t slot_bytes = (size_t)W * H;
@@ -880,10 +876,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     g.nshift = ((g.tw & (g.tw - 1)) == 0) ? (31 - __clz(g.tw)) : -1;
     g.pitch = dm.pool_w;
     const int yy = y + H / 2, xx = x0 + W / 2;
-    if (dm.dbg & 16) {
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) { px0[p] = 0x123456u + p; px1[p] = 0x654321u + x0; fu[p] = 1.f; fv[p] = 2.f; }
-    } else if (inside) {
+    if (inside) {
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
       const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
       const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
@@ -1002,7 +995,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     if (O.kind == 1) {
       const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
       uint32_t c0w = 0, c1w = 0;
-      if (inside && !(dm.dbg & 8)) {
+      if (inside) {
         if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
         if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
       }
@@ -1074,16 +1067,14 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     const int any1 = m1[0] | m1[1] | m1[2] | m1[3];
     const int anyn = na0[0] | na0[1] | na0[2] | na0[3];
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
-    if (any0 && !(dm.dbg & 4)) {  // frame 0 texture: identity warp == the crop itself (DG:339-340)
-      const uint4 q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
-      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
-    }
+    // frame 0 texture: identity warp == the crop itself (DG:339-340).  The load is issued here
+    // and consumed after the frame-1 taps: one memory round trip for both frames.
+    uint4 q0 = make_uint4(0, 0, 0, 0);
+    if (any0) q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
     uint32_t t1[kPx] = {0, 0, 0, 0};
     bool deform_tex = false;
     if constexpr (kDeform) deform_tex = (O.deform > 0);
-    if (any1 && !deform_tex && !(dm.dbg & 2)) {
+    if (any1 && !deform_tex) {
       const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
       sample4<kPow2>(tex, g, R, x0, true, t1);
     }
@@ -1126,6 +1117,11 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
 #pragma unroll
       for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (uint32_t)m1[p]);  // m == 0 leaves the pixel as is
     }
+    if (any0) {
+      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
+    }
     if (anyn) {
       // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns
 #pragma unroll
@@ -1149,28 +1145,10 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
   }
 
   if (!inside) return;
-  if ((dm.dbg & 32) && px0[0] != 0xFFFFFFFFu) return;
-  const unsigned long long t_mid = (dm.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
   // u8 -> float planes (DG:1229-1245); streaming 16-byte stores, never re-read
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const size_t plane = (size_t)W * H;
   const size_t o = (size_t)y * W + x0;
-  if (dm.dbg & 64) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
-                 (float)((px0[2] >> (8 * c)) & 255u), (float)((px0[3] >> (8 * c)) & 255u)};
-      f32x4 b = {(float)((px1[0] >> (8 * c)) & 255u), (float)((px1[1] >> (8 * c)) & 255u),
-                 (float)((px1[2] >> (8 * c)) & 255u), (float)((px1[3] >> (8 * c)) & 255u)};
-      *reinterpret_cast<f32x4*>(img0 + ((size_t)s * 3 + c) * plane + o) = a;
-      *reinterpret_cast<f32x4*>(img1 + ((size_t)s * 3 + c) * plane + o) = b;
-    }
-    f32x4 u = {fu[0], fu[1], fu[2], fu[3]};
-    f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
-    *reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o) = u;
-    *reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o) = v;
-    return;
-  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
@@ -1184,14 +1162,6 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
   f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
   __builtin_nontemporal_store(u, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o));
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
-  if (dm.dbg & 128) {
-    __builtin_amdgcn_s_waitcnt(0);
-    const unsigned long long t_end = __builtin_readcyclecounter();
-    if ((tid & 63) == 0) {
-      dm.dbg_buf[(size_t)(bid * 4 + (tid >> 6)) * 2 + 0] = t_mid - t_start;
-      dm.dbg_buf[(size_t)(bid * 4 + (tid >> 6)) * 2 + 1] = (t_end - t_mid) | ((wall_clock64() - r_start) << 32);
-    }
-  }
 }
 
 template <bool kDeform, bool kPow2>
@@ -1206,14 +1176,15 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
                                              const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
   // raster_kernel has consumed the work list: reset the counter for this slot's next launch
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
-  // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give
-  // every XCD a contiguous run of tiles (whole samples): their background rows,
-  // coverage slots and object records then stay in that XCD's L2.
+  // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch).  Every XCD takes
+  // every 8th run of 32 consecutive strips (= one 64 x 16 tile row of 8 tiles): neighbouring
+  // strips share their background rows, coverage and object records in that XCD's L2, and the
+  // foreground-heavy samples are spread over all XCDs.
   const int nblk = gridDim.x;
   int wg = blockIdx.x;
-  {
-    const int q = nblk >> 3, rm = nblk & 7, xcd = wg & 7, slot = wg >> 3;
-    wg = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + slot;
+  if (wg < (nblk & ~255)) {
+    const int xcd = wg & 7, slot = wg >> 3;
+    wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31);
   }
   // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
   // of four sibling waves retires

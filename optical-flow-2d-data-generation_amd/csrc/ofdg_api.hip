@@ -408,22 +408,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
-  { static const int dbg = getenv("OFDG_DBG") ? atoi(getenv("OFDG_DBG")) : 0; dm.dbg = dbg; }
-  const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;
-  static unsigned long long* dbg_buf = nullptr;
-  static long long dbg_launches = 0;
-  dm.dbg_buf = nullptr;
-  if (dm.dbg & 128) {
-    if (!dbg_buf) { HIP_OK(c, hipMalloc((void**)&dbg_buf, (size_t)compose_grid * 16)); }
-    dm.dbg_buf = dbg_buf;
-    if (++dbg_launches == 100) {
-      HIP_OK(c, hipDeviceSynchronize());
-      std::vector<unsigned long long> h((size_t)compose_grid * 2);
-      HIP_OK(c, hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
-      double a = 0, b = 0, r = 0; for (int i = 0; i < compose_grid; ++i) { a += h[2 * i]; b += h[2 * i + 1] & 0xffffffffull; r += h[2 * i + 1] >> 32; }
-      fprintf(stderr, "compose wave timing: compute %.0f ticks, store drain %.0f ticks, life %.2f us @100MHz (avg over %d waves)\n", a / compose_grid, b / compose_grid, r / compose_grid / 100.0, compose_grid);
-    }
-  }  // one 64 x 4 strip per single-wave workgroup
+  const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
     ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];

@@ -84,8 +84,6 @@ struct RenderDims {
   int32_t n_samples;
   int32_t n_shapes;        // total rasterised shapes in the batch
   int32_t tiles_x, tiles_y;
-  int32_t dbg;
-  unsigned long long* dbg_buf;
 };
 
 }  // namespace ofdg

@@ -72,6 +72,7 @@ struct ofdg_ctx {
     DevBuf<unsigned> d_bgwarp_max;
     hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records
     bool compose_pending = false;
+    long long composed_seq = -1;       // its launch number
     int* d_item_count = nullptr;
     int res_samples = 0, res_shapes = 0;
     // counter sampler: records already sampled (ahead of time) for samples cs_index..cs_index+cs_n-1
@@ -106,8 +107,14 @@ struct ofdg_ctx {
   DevBuf<uint8_t> d_cov2[2];
   hipStream_t prep_stream = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr};
-  hipEvent_t ev_compose_done[2] = {nullptr, nullptr};
-  bool compose_pending[2] = {false, false};
+  // the compose that last read coverage workspace 0 / 1: an alias of that slot's ev_composed
+  // (one event record per launch).  Composes run in launch order on one caller stream, so
+  // waiting for the later of two composes covers the earlier.
+  hipEvent_t cov_event[2] = {nullptr, nullptr};
+  long long cov_seq[2] = {-1, -1};
+  long long compose_seq = 0;
+  hipStream_t last_st = nullptr;
+  bool have_last_st = false;
   int parity = 0;       // workspace of the next launch
   int last_parity = 0;  // workspace the last launch used (debug read-back)
   bool overlap = true;
@@ -226,8 +233,7 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     return OFDG_EHIP;
   }
   for (int i = 0; i < 2; ++i)
-    if ((e = hipEventCreateWithFlags(&c->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_compose_done[i], hipEventDisableTiming)) != hipSuccess) {
+    if ((e = hipEventCreateWithFlags(&c->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess) {
       g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
       return OFDG_EHIP;
     }
@@ -259,7 +265,6 @@ void ofdg_destroy(ofdg_ctx* c) {
   for (int i = 0; i < 2; ++i) {
     c->d_cov2[i].release();
     if (c->ev_prep_done[i]) (void)hipEventDestroy(c->ev_prep_done[i]);
-    if (c->ev_compose_done[i]) (void)hipEventDestroy(c->ev_compose_done[i]);
   }
   for (auto& sl : c->slots) {
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
@@ -423,8 +428,18 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   uint8_t* cov = c->d_cov2[cb].p;
   if (c->overlap) {
     if (sl.upload_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_uploaded, 0));
-    if (sl.compose_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
-    if (c->compose_pending[cb]) HIP_OK(c, hipStreamWaitEvent(ps, c->ev_compose_done[cb], 0));
+    if (c->have_last_st && c->last_st != st) {
+      // the caller switched streams: composes are no longer ordered among themselves
+      HIP_OK(c, hipDeviceSynchronize());
+      for (auto& s2 : c->slots) s2.compose_pending = false;
+      c->cov_event[0] = c->cov_event[1] = nullptr;
+    }
+    c->last_st = st; c->have_last_st = true;
+    // this slot's records and coverage workspace `cb` are free once their last readers are done
+    if (c->cov_event[cb] && (!sl.compose_pending || c->cov_seq[cb] >= sl.composed_seq))
+      HIP_OK(c, hipStreamWaitEvent(ps, c->cov_event[cb], 0));
+    else if (sl.compose_pending)
+      HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
   const int* n_shapes_dev = nullptr;
@@ -478,11 +493,13 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
   if (c->overlap) {
-    HIP_OK(c, hipEventRecord(c->ev_compose_done[cb], st));
-    c->compose_pending[cb] = true;
     if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
     HIP_OK(c, hipEventRecord(sl.ev_composed, st));
     sl.compose_pending = true;
+    sl.composed_seq = c->compose_seq;
+    c->cov_event[cb] = sl.ev_composed;
+    c->cov_seq[cb] = c->compose_seq;
+    c->compose_seq++;
   }
   return OFDG_OK;
 }

@@ -14,6 +14,7 @@ torch.cuda.synchronize()
 N = int(os.environ.get("N", "300"))
 t = time.perf_counter()
 for i in range(N): g.forward_counter((20 + i) * B, B, i0, i1, fl, st)
+t_host = (time.perf_counter() - t) / N
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / N
-print(f"counter-sampler forward mode={MODE}: step={dt*1e6:.1f} us -> {B/dt:.0f} samples/s")
+print(f"counter-sampler forward mode={MODE}: step={dt*1e6:.1f} us (host enqueue {t_host*1e6:.1f} us/step) -> {B/dt:.0f} samples/s")

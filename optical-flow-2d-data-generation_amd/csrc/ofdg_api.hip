@@ -384,6 +384,7 @@ static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
     HIP_OK(c, sl.d_blockmask.reserve((words + 16) * 2));
     sl.box_stride = sl.d_blockmask.cap / 2;
     HIP_OK(c, hipMemset(sl.d_blockmask.p, 0, sl.d_blockmask.cap * sizeof(unsigned long long)));
+    HIP_OK(c, hipDeviceSynchronize());  // (the fill runs on the null stream; the kernels use non-blocking streams)
     sl.mask_used[0] = sl.mask_used[1] = 0;
   }
   return OFDG_OK;
@@ -394,7 +395,7 @@ static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
   const int stride = sl.res_shapes / sl.res_samples;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride};
-  hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples), dim3(256), 0, s, c->cs_mode, D, first_index, sl.d_shapes.p,
+  hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index, sl.d_shapes.p,
                      sl.d_objects.p, sl.d_samples.p, c->d_err);
   HIP_OK(c, hipGetLastError());
   sl.cs_index = first_index;
@@ -534,6 +535,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     if (!sl.d_item_count) {
       HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
       HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
+      HIP_OK(c, hipDeviceSynchronize());
     }
   }
   HIP_OK(c, sl.d_objects.reserve(n_obj));
@@ -680,6 +682,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (!sl.d_item_count) {
     HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
     HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
+    HIP_OK(c, hipDeviceSynchronize());
   }
   sl.res_samples = n;
   sl.res_shapes = (int)shapes_cap;
@@ -728,7 +731,7 @@ int ofdg_sample_counter(ofdg_ctx* c, long long first_index, int n_samples, ofdg_
   HIP_OK(c, hipDeviceSynchronize());
   HIP_OK(c, c->d_cs_bps.reserve((size_t)n_samples * kCsBlueprintsPerSample));
   HIP_OK(c, c->d_cs_nobj.reserve(n_samples));
-  hipLaunchKernelGGL(cs_sample_kernel, dim3(n_samples), dim3(256), 0, 0, c->cs_mode, first_index, n_samples, c->d_cs_bps.p,
+  hipLaunchKernelGGL(cs_sample_kernel, dim3(n_samples * kCsGroups), dim3(64), 0, 0, c->cs_mode, first_index, n_samples, c->d_cs_bps.p,
                      c->d_cs_nobj.p);
   HIP_OK(c, hipGetLastError());
   std::vector<int> nobj(n_samples);

@@ -3,6 +3,7 @@
 // in kernels.hip.  There is no CPU fallback: without a HIP device every entry
 // point that would render fails with OFDG_EHIP.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -102,16 +103,18 @@ struct ofdg_ctx {
   int rs_w = 0, rs_h = 0;          // CImg resize tables for the background crops
   int *d_rs_xi = nullptr, *d_rs_yi = nullptr;
   double *d_rs_xa = nullptr, *d_rs_ya = nullptr;
-  // Coverage workspaces: two, used alternately, so that the preparation kernels of
-  // launch i+1 (internal stream) overlap the compose kernel of launch i (caller's stream).
-  DevBuf<uint8_t> d_cov2[2];
+  // Coverage workspaces: three, used in rotation, so that the preparation kernels of launch
+  // i+1 (internal stream) may start as soon as compose i-2 is done and are long finished when
+  // compose i ends: the cross-stream hand-over is off the critical path.
+  static constexpr int kWorkspaces = 3;
+  DevBuf<uint8_t> d_cov2[kWorkspaces];
   hipStream_t prep_stream = nullptr;
-  hipEvent_t ev_prep_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_prep_done[kWorkspaces] = {};
   // the compose that last read coverage workspace 0 / 1: an alias of that slot's ev_composed
   // (one event record per launch).  Composes run in launch order on one caller stream, so
   // waiting for the later of two composes covers the earlier.
-  hipEvent_t cov_event[2] = {nullptr, nullptr};
-  long long cov_seq[2] = {-1, -1};
+  hipEvent_t cov_event[kWorkspaces] = {};
+  long long cov_seq[kWorkspaces] = {-1, -1, -1};
   long long compose_seq = 0;
   hipStream_t last_st = nullptr;
   bool have_last_st = false;
@@ -232,7 +235,7 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < ofdg_ctx::kWorkspaces; ++i)
     if ((e = hipEventCreateWithFlags(&c->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess) {
       g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
       return OFDG_EHIP;
@@ -262,7 +265,7 @@ void ofdg_destroy(ofdg_ctx* c) {
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < ofdg_ctx::kWorkspaces; ++i) {
     c->d_cov2[i].release();
     if (c->ev_prep_done[i]) (void)hipEventDestroy(c->ev_prep_done[i]);
   }
@@ -392,11 +395,11 @@ static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
 
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
-static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
+static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, hipEvent_t done = nullptr) {
   const int stride = sl.res_shapes / sl.res_samples;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride};
-  hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index, sl.d_shapes.p,
-                     sl.d_objects.p, sl.d_samples.p, c->d_err);
+  hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, done, 0, c->cs_mode, D,
+                        first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err);
   HIP_OK(c, hipGetLastError());
   sl.cs_index = first_index;
   sl.cs_n = sl.res_samples;
@@ -423,7 +426,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   // caller's stream `st`.  prep(i) only waits for this slot's upload and for the compose
   // that last read coverage workspace i % 2, so it overlaps compose(i - 1).
   const int cb = c->parity;
-  c->parity ^= 1;
+  c->parity = (c->parity + 1) % ofdg_ctx::kWorkspaces;
   c->last_parity = cb;
   hipStream_t ps = c->overlap ? c->prep_stream : st;
   uint8_t* cov = c->d_cov2[cb].p;
@@ -433,7 +436,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
       // the caller switched streams: composes are no longer ordered among themselves
       HIP_OK(c, hipDeviceSynchronize());
       for (auto& s2 : c->slots) s2.compose_pending = false;
-      c->cov_event[0] = c->cov_event[1] = nullptr;
+      for (auto& e2 : c->cov_event) e2 = nullptr;
     }
     c->last_st = st; c->have_last_st = true;
     // this slot's records and coverage workspace `cb` are free once their last readers are done
@@ -468,34 +471,37 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
-    hipLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
-                       sl.d_verts.p, W, H, cov, box_next, n_mask_words);
+    // (completion events ride on the kernels' own dispatch packets: no marker packets
+    // between the kernels of a stream)
+    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, nullptr,
+                          c->overlap ? c->ev_prep_done[cb] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
+                          sl.d_verts.p, W, H, cov, box_next, n_mask_words);
     HIP_OK(c, hipGetLastError());
   }
   if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[2], ps));
-  if (c->overlap) {
-    HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
-    HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
-  }
+  if (c->overlap) HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
   if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
+  hipEvent_t done = nullptr;
+  if (c->overlap) {
+    if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
+    done = sl.ev_composed;
+  }
   if (c->prm.mode == 9)
-    hipLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, dm,
-                       sl.d_samples.p, sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow,
-                       sl.d_frames.p, sl.d_croptab.p, sl.d_item_count);
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
+                          sl.d_item_count);
   else if ((W & (W - 1)) == 0)
-    hipLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, dm, sl.d_samples.p, sl.d_objects.p, box_cur, cov,
-                       c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
-    // The compose kernels allocate <= 104 VGPRs -> 4 waves per SIMD; the remaining 96 registers
-    // per lane and all of the LDS are what lets the latency-bound preparation kernels of the
-    // next batch (internal stream) co-reside with them.
-    hipLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, dm, sl.d_samples.p,
-                       sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+    // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
+    // makes room for the single-wave workgroups of the latency-bound preparation kernels of
+    // the next batches (internal streams), which therefore co-run with it.
+    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
   if (c->overlap) {
-    if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
-    HIP_OK(c, hipEventRecord(sl.ev_composed, st));
     sl.compose_pending = true;
     sl.composed_seq = c->compose_seq;
     c->cov_event[cb] = sl.ev_composed;
@@ -525,8 +531,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     const size_t need_cov = n_shapes * 2 * (size_t)W * H + 16;
     if (need_cov > c->d_cov2[0].cap) {
       HIP_OK(c, hipDeviceSynchronize());
-      HIP_OK(c, c->d_cov2[0].reserve(need_cov));
-      HIP_OK(c, c->d_cov2[1].reserve(need_cov));
+      for (auto& ws : c->d_cov2) HIP_OK(c, ws.reserve(need_cov));
     }
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
     (void)tiles;
@@ -674,8 +679,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   const size_t need_cov = shapes_cap * 2 * (size_t)W * H + 16;
   if (need_cov > c->d_cov2[0].cap) {
     HIP_OK(c, hipDeviceSynchronize());
-    HIP_OK(c, c->d_cov2[0].reserve(need_cov));
-    HIP_OK(c, c->d_cov2[1].reserve(need_cov));
+    for (auto& ws : c->d_cov2) HIP_OK(c, ws.reserve(need_cov));
   }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
@@ -714,10 +718,9 @@ int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, floa
     if (rc != OFDG_OK) return rc;
     if (nx.sampled_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_sampled, 0));
     if (nx.compose_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_composed, 0));
-    rc = launch_counter_sampler(c, nx, first_index + delta, c->cs_stream);
-    if (rc != OFDG_OK) return rc;
     if (!nx.ev_sampled) HIP_OK(c, hipEventCreateWithFlags(&nx.ev_sampled, hipEventDisableTiming));
-    HIP_OK(c, hipEventRecord(nx.ev_sampled, c->cs_stream));
+    rc = launch_counter_sampler(c, nx, first_index + delta, c->cs_stream, nx.ev_sampled);
+    if (rc != OFDG_OK) return rc;
     nx.sampled_pending = true;
   }
   return OFDG_OK;

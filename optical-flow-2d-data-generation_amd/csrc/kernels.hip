@@ -638,9 +638,10 @@ struct RowDDA {
   int x1, lx, rx;  // start, lft, rem (rem in [1, n])
   int y1, ly, ry;
 };
+template <bool kPow2 = false>
 __device__ __forceinline__ void dda_setup(int a, int b, int n, int nshift, int& lft, int& rem) {
   const int D = b - a;
-  if (nshift >= 0) {  // n is a power of two (wave-uniform): floor quotient / remainder by shifts
+  if (kPow2 || nshift >= 0) {  // n is a power of two (wave-uniform): floor quotient / remainder by shifts
     const int q = D >> nshift, r = D & (n - 1);
     lft = r > 0 ? q : q - 1;  // dda2_line_interpolator: rem in [1, n]
     rem = r > 0 ? r : n;
@@ -650,6 +651,7 @@ __device__ __forceinline__ void dda_setup(int a, int b, int n, int nshift, int& 
     if (rem <= 0) { rem += n; lft--; }
   }
 }
+template <bool kPow2 = false>
 __device__ __forceinline__ RowDDA make_row(const Mat& inv, int row, int len, int nshift) {
   RowDDA R;
   double tx = 0 + 0.5, ty = row + 0.5;
@@ -659,19 +661,21 @@ __device__ __forceinline__ RowDDA make_row(const Mat& inv, int row, int len, int
   tx = 0 + 0.5 + len; ty = row + 0.5;
   xform(inv, tx, ty);
   const int x2 = iround_d(tx * 256.0), y2 = iround_d(ty * 256.0);
-  dda_setup(R.x1, x2, len, nshift, R.lx, R.rx);
-  dda_setup(R.y1, y2, len, nshift, R.ly, R.ry);
+  dda_setup<kPow2>(R.x1, x2, len, nshift, R.lx, R.rx);
+  dda_setup<kPow2>(R.y1, y2, len, nshift, R.ly, R.ry);
   return R;
 }
 // value of the interpolator after i increments
+template <bool kPow2 = false>
 __device__ __forceinline__ int dda_at(int y1, int lft, int rem, int n, int nshift, int i) {
   const int a = (i + 1) * rem + n - 1;
-  const int q = (nshift >= 0) ? (a >> nshift) : (a / n);
+  const int q = (kPow2 || nshift >= 0) ? (a >> nshift) : (a / n);
   return y1 + i * lft + q - 1;
 }
+template <bool kPow2 = false>
 __device__ __forceinline__ int wrap_reflect(int v, int size, int size2, int mask2, int& raw) {
   int m;
-  if (mask2 >= 0) {  // power-of-two period (wave-uniform)
+  if (kPow2 || mask2 >= 0) {  // power-of-two period (wave-uniform)
     m = v & mask2;
   } else if ((unsigned)(v + size2) < 3u * (unsigned)size2) {  // within one period of the image: no division
     m = v;
@@ -699,14 +703,15 @@ struct WarpGeom {
 };
 
 // span_image_filter_rgb_bilinear with wrap_mode_reflect: returns packed B | G<<8 | R<<16.
+template <bool kPow2 = false>
 __device__ __forceinline__ uint32_t sample_bilinear(const uint32_t* __restrict__ tex, const WarpGeom& g,
                                                     const RowDDA& R, int i) {
-  int x_hr = dda_at(R.x1, R.lx, R.rx, g.tw, g.nshift, i) - 128;
-  int y_hr = dda_at(R.y1, R.ly, R.ry, g.tw, g.nshift, i) - 128;
+  int x_hr = dda_at<kPow2>(R.x1, R.lx, R.rx, g.tw, g.nshift, i) - 128;
+  int y_hr = dda_at<kPow2>(R.y1, R.ly, R.ry, g.tw, g.nshift, i) - 128;
   const int x_lr = x_hr >> 8, y_lr = y_hr >> 8;
   x_hr &= 255; y_hr &= 255;
   int rx, ry;
-  const int xa = wrap_reflect(x_lr, g.tw, g.tw2, g.mx2, rx);
+  const int xa = wrap_reflect<kPow2>(x_lr, g.tw, g.tw2, g.mx2, rx);  // (the width's period is a power of two with it)
   const int ya = wrap_reflect(y_lr, g.th, g.th2, g.my2, ry);
   const int xb = wrap_next(rx, g.tw, g.tw2);
   const int yb = wrap_next(ry, g.th, g.th2);
@@ -780,7 +785,7 @@ __device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const 
       for (int p = 0; p < kPx; ++p) out[p] = bilerp_rgb(t0[p], t1[p], (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
     } else {
 #pragma unroll 1
-      for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear(tex, g, R, i0 + p);
+      for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear<true>(tex, g, R, i0 + p);
     }
   }
 }
@@ -880,7 +885,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
       const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
       const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
-      const RowDDA R = make_row(B.tex_inv, yy, g.tw, g.nshift);
+      const RowDDA R = make_row<kPow2>(B.tex_inv, yy, g.tw, g.nshift);
       // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
       const double by = (double)(y + H / 2) + (double)(-H);
       sample4<kPow2>(tex, g, R, xx, true, px1);
@@ -1063,9 +1068,12 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       }
     }
 
-    const int any0 = m0[0] | m0[1] | m0[2] | m0[3];
-    const int any1 = m1[0] | m1[1] | m1[2] | m1[3];
-    const int anyn = na0[0] | na0[1] | na0[2] | na0[3];
+    // the masks wait for the texture taps as three packed words (byte p = pixel p), not 12 registers
+    static_assert(kPx == 4, "mask bytes are packed four to a word");
+    const uint32_t m0w = (uint32_t)m0[0] | ((uint32_t)m0[1] << 8) | ((uint32_t)m0[2] << 16) | ((uint32_t)m0[3] << 24);
+    const uint32_t m1w = (uint32_t)m1[0] | ((uint32_t)m1[1] << 8) | ((uint32_t)m1[2] << 16) | ((uint32_t)m1[3] << 24);
+    const uint32_t n0w = (uint32_t)na0[0] | ((uint32_t)na0[1] << 8) | ((uint32_t)na0[2] << 16) | ((uint32_t)na0[3] << 24);
+    const uint32_t any0 = m0w, any1 = m1w, anyn = n0w;
     const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
     // frame 0 texture: identity warp == the crop itself (DG:339-340).  The load is issued here
     // and consumed after the frame-1 taps: one memory round trip for both frames.
@@ -1075,7 +1083,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     bool deform_tex = false;
     if constexpr (kDeform) deform_tex = (O.deform > 0);
     if (any1 && !deform_tex) {
-      const RowDDA R = make_row(O.tex_inv, y, W, g.nshift);
+      const RowDDA R = make_row<kPow2>(O.tex_inv, y, W, g.nshift);
       sample4<kPow2>(tex, g, R, x0, true, t1);
     }
     if constexpr (kDeform) {
@@ -1084,7 +1092,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
         const size_t cn = (size_t)C.w * C.h;
 #pragma unroll 1
         for (int p = 0; p < kPx; ++p) {
-          if (!m1[p]) continue;
+          if (!((m1w >> (8 * p)) & 255u)) continue;
           const int x = x0 + p;
           const float iwx = C.data[2 * cn + (size_t)y * C.w + x], iwy = C.data[3 * cn + (size_t)y * C.w + x];
           const Taps t = make_taps((float)x + iwx, (float)y + iwy);
@@ -1115,18 +1123,18 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     }
     if (any1) {
 #pragma unroll
-      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (uint32_t)m1[p]);  // m == 0 leaves the pixel as is
+      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (m1w >> (8 * p)) & 255u);  // m == 0 leaves the pixel as is
     }
     if (any0) {
       const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
-      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (uint32_t)m0[p]);
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (m0w >> (8 * p)) & 255u);
     }
     if (anyn) {
       // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
-        if (na0[p] == 255) {
+        if (((n0w >> (8 * p)) & 255u) == 255u) {
           double ix = (double)(x0 + p), iy = (double)y;
           const float save_x = (float)(x0 + p), save_y = (float)y;
           xform(O.motion, ix, iy);

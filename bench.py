@@ -157,7 +157,7 @@ def main():
         samples = args.steps * BATCH * world
         value = samples / dt
         achieved = BATCH * ALG_BYTES_PER_SAMPLE / (compose_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None  # HBM bytes per compose launch from the committed PMC passes (profiles/traffic.json)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("compose_kernel_hbm_bytes_per_launch")
@@ -174,7 +174,7 @@ def main():
                                    "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "compose_kernel", "kernel_ms": compose_ms,
+                         "kernel": "compose_pow2_kernel", "kernel_ms": compose_ms,
                          "algorithmic_bytes_per_launch": BATCH * ALG_BYTES_PER_SAMPLE},
             "kernel_ms": parts,
             "hbm_gbs_whole_step": value / world * ALG_BYTES_PER_SAMPLE / 1e9,

@@ -123,7 +123,8 @@ struct ofdg_ctx {
   bool overlap = true;
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
-  // profiling: ring of event sets, 4 events per launch (before geom / raster / compose, after compose)
+  // profiling: ring of event sets, 6 events per launch: start/stop of geom, raster and compose,
+  // attached to the kernels' own dispatch packets
   int profiling = 0;  // 0 off, 1 compose kernel only, 2 all three kernels
   std::vector<hipEvent_t> ev;
   int ev_sets = 0, ev_stride = 1;
@@ -420,7 +421,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
-    ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 4];
+    ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 6];
   c->launch_count++;
   // Preparation (geom -> bin -> raster) runs on the internal stream `ps`, compose on the
   // caller's stream `st`.  prep(i) only waits for this slot's upload and for the compose
@@ -445,7 +446,6 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     else if (sl.compose_pending)
       HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
   }
-  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[0], ps));
   const int* n_shapes_dev = nullptr;
   if (cs_first_index >= 0) {
     if (sl.sampled_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_sampled, 0));
@@ -464,43 +464,48 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   unsigned long long* box_next = sl.d_blockmask.p + (size_t)(bp ^ 1) * sl.box_stride;
   sl.mask_used[bp] = sl.res_samples * dm.tiles_x * ((H + kBandRows - 1) / kBandRows) * 2;
   const int n_mask_words = sl.mask_used[bp ^ 1];
-  hipLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps, sl.d_shapes.p,
-                     sl.res_shapes, c->d_cs_tab, W, H, sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count,
-                     sl.d_items.p, sl.d_croptab.p, n_shapes_dev);
+  const bool prof_prep = ev && c->profiling == 2;
+  hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps,
+                        prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
+                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, sl.d_croptab.p, n_shapes_dev);
   HIP_OK(c, hipGetLastError());
-  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[1], ps));
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
     // (completion events ride on the kernels' own dispatch packets: no marker packets
     // between the kernels of a stream)
-    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, nullptr,
-                          c->overlap ? c->ev_prep_done[cb] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count,
-                          sl.d_verts.p, W, H, cov, box_next, n_mask_words);
+    // a profiled launch times the kernel itself (start/stop on its packet) and records the
+    // hand-over event separately
+    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, prof_prep ? ev[2] : nullptr,
+                          prof_prep ? ev[3] : (c->overlap ? c->ev_prep_done[cb] : nullptr), 0, sl.d_frames.p, sl.d_items.p,
+                          sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words);
     HIP_OK(c, hipGetLastError());
+    if (prof_prep && c->overlap) HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
   }
-  if (ev && c->profiling == 2) HIP_OK(c, hipEventRecord(ev[2], ps));
   if (c->overlap) HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
-  if (ev && c->profiling == 1) HIP_OK(c, hipEventRecord(ev[2], st));
   hipEvent_t done = nullptr;
   if (c->overlap) {
     if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
     done = sl.ev_composed;
   }
+  hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9)
-    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
     // makes room for the single-wave workgroups of the latency-bound preparation kernels of
     // the next batches (internal streams), which therefore co-run with it.
-    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, nullptr, done, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
-  if (ev) { HIP_OK(c, hipEventRecord(ev[3], st)); c->ev_count++; }
+  if (ev) {
+    if (done) HIP_OK(c, hipEventRecord(done, st));
+    c->ev_count++;
+  }
   if (c->overlap) {
     sl.compose_pending = true;
     sl.composed_seq = c->compose_seq;
@@ -981,14 +986,15 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
   c->ev_stride = (mode == 1) ? 4 : 1;  // mode 1 samples every 4th launch: keeps the event cost out of throughput runs
   if (mode && c->ev.empty()) {
     c->ev_sets = 256;
-    c->ev.resize((size_t)c->ev_sets * 4);
+    c->ev.resize((size_t)c->ev_sets * 6);
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
   }
   return OFDG_OK;
 }
 
 // Average device time (ms) per launch of one kernel over the launches recorded since
-// ofdg_set_profiling (at most the last 256), from HIP events on the launch stream.
+// ofdg_set_profiling (at most the last 256), from HIP events attached to the kernels' dispatch
+// packets on their launch streams (start and end of the kernel itself).
 int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   if (!c || !kernel || !ms) return OFDG_EINVAL;
   int i = -1;
@@ -1003,10 +1009,10 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   const int n = (int)std::min<long long>(c->ev_count, c->ev_sets);
   double acc = 0;
   for (int k = 0; k < n; ++k) {
-    hipEvent_t* ev = &c->ev[(size_t)k * 4];
-    HIP_OK(c, hipEventSynchronize(ev[3]));
+    hipEvent_t* ev = &c->ev[(size_t)k * 6];
+    HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
-    HIP_OK(c, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+    HIP_OK(c, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
     acc += t;
   }
   *ms = (float)(acc / n);

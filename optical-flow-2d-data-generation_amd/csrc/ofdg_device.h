@@ -12,7 +12,7 @@ constexpr int kCurveMaxPts = 96;    // points one curve3 may flatten to
 constexpr int kCurveMaxDepth = 16;  // DFS stack depth for curve3 subdivision
 constexpr int kBandRows = 8;        // scanlines one raster workgroup accumulates in LDS
 constexpr int kMaxFgObjects = 64;   // foreground objects per sample (bits of a tile mask)
-constexpr int kRasterGrid = 2048;   // persistent raster workgroups
+constexpr int kRasterGrid = 512;    // x4 persistent single-wave raster workgroups: enough to finish in time, few enough not to crowd compose
 
 // error bits raised by kernels (device word, read by ofdg_synchronize)
 constexpr uint32_t kErrVertCapacity = 1u;   // outline has more than kMaxVerts vertices

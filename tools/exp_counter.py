@@ -7,15 +7,16 @@ W, H, B = 512, 384, 32
 MODE = int(os.environ.get("MODE", "5")); NOBJ = int(os.environ.get("NOBJ", "16"))
 g = ofdg.Generator(ofdg.default_params(mode=MODE, batch_size=B, width=W, height=H, num_objects=NOBJ, sampler=1, seed=5))
 g.pool_synthetic(1000, 1024, 768, seed=1)
-i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+NBUF = int(os.environ.get("NBUF", "2"))  # output buffer sets the caller cycles (prefetch ring)
+outs = [ofdg.alloc_outputs(B, H, W) for _ in range(NBUF)]
 st = torch.cuda.current_stream().cuda_stream
-for i in range(20): g.forward_counter(i * B, B, i0, i1, fl, st)
+for i in range(20): g.forward_counter(i * B, B, *outs[i % NBUF], st)
 torch.cuda.synchronize()
 N = int(os.environ.get("N", "300"))
 g.set_profiling(1)
 t = time.perf_counter()
-for i in range(N): g.forward_counter((20 + i) * B, B, i0, i1, fl, st)
+for i in range(N): g.forward_counter((20 + i) * B, B, *outs[i % NBUF], st)
 t_host = (time.perf_counter() - t) / N
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / N
-print(f"counter-sampler forward mode={MODE}: step={dt*1e6:.1f} us (compose kernel {g.kernel_ms('compose')*1e3:.1f} us, host enqueue {t_host*1e6:.1f} us/step) -> {B/dt:.0f} samples/s")
+print(f"counter-sampler forward mode={MODE} nbuf={NBUF}: step={dt*1e6:.1f} us (compose kernel {g.kernel_ms('compose')*1e3:.1f} us, host enqueue {t_host*1e6:.1f} us/step) -> {B/dt:.0f} samples/s")

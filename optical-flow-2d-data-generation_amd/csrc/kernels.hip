@@ -1004,6 +1004,11 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
         if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
         if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
       }
+      // the box touches the block but the outline covers none of this strip's pixels (about
+      // half of the visits): nothing to mask, sample or blend
+      bool moved_mask = false;
+      if constexpr (kDeform) moved_mask = O.deform > 0;  // mode 9 re-samples the frame-1 mask from elsewhere
+      if (!moved_mask && __ballot((c0w | c1w) != 0u) == 0ull) continue;
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
         const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);

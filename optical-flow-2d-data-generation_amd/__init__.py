@@ -203,6 +203,12 @@ class Generator:
         self._check(lib().ofdg_pool_download(self.h, index, a.ctypes.data_as(C.c_void_p)))
         return a
 
+    def pool_info(self):
+        """(n, w, h) of the resident texture pool."""
+        n, w, h = C.c_int32(), C.c_int32(), C.c_int32()
+        lib().ofdg_pool_info(self.h, C.byref(n), C.byref(w), C.byref(h))
+        return n.value, w.value, h.value
+
     def pool_download_all(self):
         import numpy as np
         n, w, h = C.c_int(), C.c_int(), C.c_int()

@@ -126,12 +126,14 @@ def test_rasteriser_offscreen_and_clipped(ofdg, oracle):
         assert np.array_equal(cov, exp), "case %d: %d px differ" % (i, (cov != exp).sum())
 
 
+@pytest.mark.parametrize("size", [(128, 96), (160, 100)], ids=["128x96-pow2-kernel", "160x100-any-width-kernel"])
 @pytest.mark.parametrize("mode", [1, 2, 3, 5, 7, 13])
-def test_render_matches_oracle_small(ofdg, oracle, mode):
-    """End to end on a 128x96 frame: objects are large relative to the frame, so
-    overlaps, clipping and composites are dense."""
-    W, H = 128, 96
-    g = make_gen(ofdg, W, H, mode, pool=(5, 256, 192))
+def test_render_matches_oracle_small(ofdg, oracle, mode, size):
+    """End to end on a small frame: objects are large relative to the frame, so overlaps,
+    clipping, reflection at the texture borders and composites are dense.  Both compose
+    kernels: widths that are a power of two take compose_pow2_kernel, others compose_kernel."""
+    W, H = size
+    g = make_gen(ofdg, W, H, mode, pool=(5, 2 * W, 2 * H))
     pool = g.pool_download_all()
     s = oracle.Sampler(mode, W, H)
     tasks, bps, n = s.next(6)
@@ -149,6 +151,17 @@ def test_render_matches_oracle_full_size(ofdg, oracle, mode, use_aa):
     tasks, bps, n = s.next(2)
     got = render_gpu(ofdg, g, tasks, 2, bps, n)
     compare(oracle, g.params, tasks, 2, bps, n, pool, got, flow_ulp=0)
+
+
+def test_config4_1024x768_32_objects(ofdg, oracle):
+    """BASELINE config 4 shape: mode 7 at 1024x768 with 32 objects per sample (one sample against the oracle)."""
+    W, H = 1024, 768
+    g = make_gen(ofdg, W, H, 7, num_objects=32, pool=(2, 2048, 1536))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(7, W, H, 32)
+    tasks, bps, n = s.next(1)
+    got = render_gpu(ofdg, g, tasks, 1, bps, n)
+    compare(oracle, g.params, tasks, 1, bps, n, pool, got, flow_ulp=0)
 
 
 def test_config1_single_object(ofdg, oracle):
@@ -254,6 +267,30 @@ def test_full_size_properties(ofdg):
     d2x = f[:, :, 2:] - 2 * f[:, :, 1:-1] + f[:, :, :-2]
     d2y = f[:, 2:, :] - 2 * f[:, 1:-1, :] + f[:, :-2, :]
     assert float(d2x.abs().max()) < 1e-4 and float(d2y.abs().max()) < 1e-4
+
+
+def test_config5_large_pool_resident_in_hbm(ofdg):
+    """BASELINE config 5 shape: 10 000 textures of 1 MP (1024x1024 BGRX = 42 GB) resident in HBM, mode 7,
+    512x384, one rank's batch of 32 from the counter sampler.  Properties: repeatable, integer frames in
+    [0, 255], finite flow, and the textures actually come from all over the pool."""
+    torch = torch_mod()
+    W, H, B = 512, 384, 32
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=3, batch_size=B))
+    g.pool_synthetic(10000, 1024, 1024, 11)
+    assert g.pool_info()[0] == 10000
+    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(2)]
+    for o in outs:
+        g.forward_counter(1000, B, *o)
+    g.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    i0, i1, fl = outs[0]
+    for t in (i0, i1):
+        assert float(t.min()) >= 0 and float(t.max()) <= 255 and torch.equal(t, t.round())
+    assert torch.isfinite(fl).all()
+    tasks, bps, n = g.sample_counter(1000, B)
+    tex = {bps[t.background].tex_id % 10000 for t in tasks}
+    assert len(tex) > B // 2 and max(tex) > 5000
 
 
 LAYER_PROTOTXT = '''

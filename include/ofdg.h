@@ -109,7 +109,11 @@ typedef struct ofdg_params {
   int32_t rank, world_size;     /* sample sharding (g = step*B*world + rank*B + i) */
   int32_t device;               /* HIP device ordinal */
   int32_t max_shapes_per_sample;/* 0 = default capacity */
-  int32_t reserved[9];
+  int32_t background_prep;      /* background texture m_textures[0] (DG:1186-1192):
+                                   0 = centre 2W x 2H crop of the pool image (parity boundary, default);
+                                   1 = Texture::getRandomizedCrop(2W, 2H, tex_rot, tex_scale, tex_shift)
+                                       (DG:87-109): shift, rotate, centre crop, zoom (CImg chain, unpinned) */
+  int32_t reserved[8];
 } ofdg_params;
 
 typedef struct ofdg_ctx ofdg_ctx;
@@ -246,6 +250,12 @@ int ofdg_host_realize(const ofdg_params* prm, int pool_n, int pool_w, int pool_h
                       const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
                       int n_bps, double* shape_mats, int shape_cap, int* n_shapes,
                       double* object_mats, int object_cap, int* n_objects);
+/* Host logic of ofdg_params.background_prep = 1 (no GPU): the coordinate-map record of
+ * Texture::getRandomizedCrop(2W, 2H, angle, zoom, shift) (DG:87-109) on a pool_w x pool_h image.
+ * f[8] = ca, sa, w2, h2, rw2, rh2, fx, fy; i[6] = x0, y0, cw, ch, shift_x, shift_y. */
+int ofdg_host_bg_prep(int pool_w, int pool_h, int width, int height, float angle, float zoom,
+                      int shift_x, int shift_y, float* f, int* i);
+
 /* Parse a `layer { ... }` prototxt block (example-prototxt/train.prototxt). */
 int ofdg_parse_prototxt(const char* text, ofdg_params* out, char* texture_dbases,
                         int texture_dbases_cap, int* n_top);

@@ -54,7 +54,7 @@ class Params(C.Structure):
         ("first_level_threads", C.c_int32), ("second_level_threads", C.c_int32),
         ("num_objects", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("device", C.c_int32),
-        ("max_shapes_per_sample", C.c_int32), ("reserved", C.c_int32 * 9),
+        ("max_shapes_per_sample", C.c_int32), ("background_prep", C.c_int32), ("reserved", C.c_int32 * 8),
     ]
 
 
@@ -69,7 +69,7 @@ _lib = None
 # every symbol include/ofdg.h declares
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
-    "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
+    "ofdg_host_bg_prep", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",

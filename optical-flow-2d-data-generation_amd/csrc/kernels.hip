@@ -836,7 +836,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
                                              const DevObject* __restrict__ objects,
                                              const unsigned long long* __restrict__ blockmask,
                                              const uint8_t* __restrict__ cov,
-                                             const uint32_t* __restrict__ pool,
+                                             const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
@@ -873,13 +873,13 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
   // ---- background (object 0): masks are all 255, so frames start as its textures ----
   {
     const DevObject& B = objs[0];
-    const uint32_t* tex = pool + B.tex_base;  // origin of the 2W x 2H centre crop
+    const uint32_t* tex = bgpool + B.tex_base;  // origin of the 2W x 2H texture (centre crop of the pool image, or the sample's prepared one)
     WarpGeom g;
     g.tw = 2 * W; g.th = 2 * H; g.tw2 = 4 * W; g.th2 = 4 * H;
     g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
     g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
     g.nshift = ((g.tw & (g.tw - 1)) == 0) ? (31 - __clz(g.tw)) : -1;
-    g.pitch = dm.pool_w;
+    g.pitch = dm.bg_pitch;
     const int yy = y + H / 2, xx = x0 + W / 2;
     if (inside) {
       // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
                                              const DevObject* __restrict__ objects,
                                              const unsigned long long* __restrict__ blockmask,
                                              const uint8_t* __restrict__ cov,
-                                             const uint32_t* __restrict__ pool,
+                                             const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
@@ -1201,31 +1201,31 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   }
   // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
   // of four sibling waves retires
-  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
+  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void compose_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_body<false, false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
+  compose_body<false, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, nullptr, item_count);
 }
 // W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads.
 __global__ __launch_bounds__(64) void compose_pow2_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_body<false, true>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, nullptr, item_count);
+  compose_body<false, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, nullptr, item_count);
 }
 // Mode 9: the same kernel with the deformation paths compiled in.
 __global__ __launch_bounds__(64) void compose_deform_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, img0, img1, flow, frames, crops, item_count);
+  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
 }
 
 // --------------------------------------------------------------------------
@@ -1380,6 +1380,55 @@ __device__ __forceinline__ uint32_t lattice(uint32_t seed, uint32_t tex, uint32_
 // Synthetic texture = 3 octaves of integer value noise (cell sizes 64, 16, 4; weights
 // 4:2:1), i.e. a smooth field with fine detail so that bilinear filtering and LSB
 // errors are visible.  Pure integer arithmetic: reproducible anywhere.
+// Background texture preparation (ofdg_params.background_prep = 1): one thread per texel of the
+// sample's 2W x 2H texture; see DevBgPrep.  Texture::getRandomizedCrop, DG:87-109 (CImg chain
+// restated as one resampling; parity unpinned).  Strict fp32, same operation order as the oracle.
+__device__ __forceinline__ float cimg_modf(float x, float m) { return (float)((double)x - (double)m * floor((double)x / (double)m)); }
+__device__ __forceinline__ int mirror_index(int i, int n) {
+  int m = i % (2 * n);
+  if (m < 0) m += 2 * n;
+  return m < n ? m : 2 * n - m - 1;
+}
+__global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, const uint32_t* __restrict__ pool,
+                                                     int pw, int ph, int W, int H, uint32_t* __restrict__ bgtex) {
+  const int TW = 2 * W, TH = 2 * H;
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= TW * TH) return;
+  const int u = i % TW, v = i / TW;
+  const DevBgPrep p = prep[s];
+  const uint32_t* img = pool + p.image_base;
+  const float ww = 2.0f * pw, hh = 2.0f * ph;
+  const float cxf = fminf((float)(p.cw - 1), __fmul_rn((float)u, p.fx)), cyf = fminf((float)(p.ch - 1), __fmul_rn((float)v, p.fy));
+  const float xc = __fsub_rn(__fadd_rn((float)p.x0, cxf), p.rw2), yc = __fsub_rn(__fadd_rn((float)p.y0, cyf), p.rh2);
+  float mx = cimg_modf(__fadd_rn(__fadd_rn(p.w2, __fmul_rn(xc, p.ca)), __fmul_rn(yc, p.sa)), ww);
+  float my = cimg_modf(__fadd_rn(__fsub_rn(p.h2, __fmul_rn(xc, p.sa)), __fmul_rn(yc, p.ca)), hh);
+  mx = mx < (float)pw ? mx : __fsub_rn(__fsub_rn(ww, mx), 1.0f);
+  my = my < (float)ph ? my : __fsub_rn(__fsub_rn(hh, my), 1.0f);
+  // _linear_atXY (Neumann) on the shifted image
+  const float nfx = mx <= 0 ? 0.f : (mx >= (float)(pw - 1) ? (float)(pw - 1) : mx);
+  const float nfy = my <= 0 ? 0.f : (my >= (float)(ph - 1) ? (float)(ph - 1) : my);
+  const int x = (int)nfx, y = (int)nfy;
+  const float dx = __fsub_rn(nfx, (float)x), dy = __fsub_rn(nfy, (float)y);
+  const int nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
+  const int xa = mirror_index(x - p.shx, pw), xb = mirror_index(nx - p.shx, pw);
+  const int ya = mirror_index(y - p.shy, ph), yb = mirror_index(ny - p.shy, ph);
+  const uint32_t tcc = img[(size_t)ya * pw + xa], tnc = img[(size_t)ya * pw + xb];
+  const uint32_t tcn = img[(size_t)yb * pw + xa], tnn = img[(size_t)yb * pw + xb];
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sh = 8 * c;
+    const float Icc = (float)((tcc >> sh) & 255u), Inc = (float)((tnc >> sh) & 255u);
+    const float Icn = (float)((tcn >> sh) & 255u), Inn = (float)((tnn >> sh) & 255u);
+    // Icc + dx*(Inc - Icc + dy*(Icc + Inn - Icn - Inc)) + dy*(Icn - Icc)
+    const float t = __fsub_rn(__fsub_rn(__fadd_rn(Icc, Inn), Icn), Inc);
+    const float val = __fadd_rn(__fadd_rn(Icc, __fmul_rn(dx, __fadd_rn(__fsub_rn(Inc, Icc), __fmul_rn(dy, t)))), __fmul_rn(dy, __fsub_rn(Icn, Icc)));
+    out |= (uint32_t)(unsigned char)val << sh;
+  }
+  bgtex[(size_t)s * TW * TH + i] = out;
+}
+
 __global__ __launch_bounds__(256) void pool_synth_kernel(uint32_t* __restrict__ pool, int n, int w, int h, uint32_t seed) {
   const size_t total = (size_t)n * w * h;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

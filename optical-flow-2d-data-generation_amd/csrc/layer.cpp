@@ -139,6 +139,7 @@ void parse_message(Lexer& lx, const std::string& scope, LayerConfig* cfg, bool t
       else if (f == "height") p.height = to_int(v, key);
       else if (f == "num_objects") p.num_objects = to_int(v, key);
       else if (f == "seed") p.seed = to_int(v, key);
+      else if (f == "background_prep") p.background_prep = (v.text == "true" || v.text == "1") ? 1 : 0;
       else if (f == "sampler") p.sampler = (v.text == "counter") ? OFDG_SAMPLER_COUNTER : OFDG_SAMPLER_REF;
       else throw std::runtime_error("prototxt: unknown data_generation_param field '" + f + "'");
     }
@@ -388,6 +389,17 @@ int ofdg_layer_forward(ofdg_layer* L, float** image0, float** image1, float** fl
   if (image1) *image1 = L->top[1].mutable_gpu_data();
   if (flow) *flow = L->top[2].mutable_gpu_data();
   if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = L->top[0].shape()[i];
+  return OFDG_OK;
+}
+
+// The background preparation record of getRandomizedCrop(2W, 2H, angle, zoom, shift) on a pool_w x pool_h image
+// (host logic, no GPU): f[8] = ca, sa, w2, h2, rw2, rh2, fx, fy; i[6] = x0, y0, cw, ch, shift_x, shift_y.
+int ofdg_host_bg_prep(int pool_w, int pool_h, int width, int height, float angle, float zoom, int shift_x, int shift_y, float* f,
+                      int* i) {
+  if (!f || !i || pool_w < 2 * width || pool_h < 2 * height || !(zoom > 0)) return OFDG_EINVAL;
+  const ofdg::DevBgPrep p = ofdg::make_bg_prep(pool_w, pool_h, width, height, angle, zoom, shift_x, shift_y, 0);
+  f[0] = p.ca; f[1] = p.sa; f[2] = p.w2; f[3] = p.h2; f[4] = p.rw2; f[5] = p.rh2; f[6] = p.fx; f[7] = p.fy;
+  i[0] = p.x0; i[1] = p.y0; i[2] = p.cw; i[3] = p.ch; i[4] = p.shx; i[5] = p.shy;
   return OFDG_OK;
 }
 

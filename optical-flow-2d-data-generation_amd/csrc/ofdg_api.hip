@@ -61,6 +61,8 @@ struct ofdg_ctx {
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
     DevBuf<int4> d_items;
+    DevBuf<DevBgPrep> d_bgprep;   // background_prep: one record ...
+    DevBuf<uint32_t> d_bgtex;     // ... and one prepared 2W x 2H BGRX texture per sample
     DevBuf<unsigned long long> d_blockmask;  // [2 parities][samples][64 x 8 blocks][2 frames]
     int res_objects = 0;
     int box_parity = 0;
@@ -262,7 +264,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
-    sl.d_items.release(); sl.d_blockmask.release();
+    sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
   }
@@ -396,12 +398,19 @@ static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
 
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, hipEvent_t done = nullptr) {
   const int stride = sl.res_shapes / sl.res_samples;
-  CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride};
-  hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, done, 0, c->cs_mode, D,
-                        first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err);
+  const int prep = c->prm.background_prep ? 1 : 0;
+  CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep};
+  hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, prep ? nullptr : done, 0,
+                        c->cs_mode, D, first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
+  if (prep) {
+    int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s);
+    if (rc != OFDG_OK) return rc;
+    if (done) HIP_OK(c, hipEventRecord(done, s));
+  }
   sl.cs_index = first_index;
   sl.cs_n = sl.res_samples;
   return OFDG_OK;
@@ -418,6 +427,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
+  dm.bg_pitch = c->prm.background_prep ? 2 * W : c->pool_w;
   const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
@@ -482,6 +492,8 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     if (prof_prep && c->overlap) HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
   }
   if (c->overlap) HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
+  const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : c->pool;  // (after the slot's buffers are final)
+  if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
   hipEvent_t done = nullptr;
   if (c->overlap) {
     if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
@@ -490,17 +502,17 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9)
     hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
     // makes room for the single-wave workgroups of the latency-bound preparation kernels of
     // the next batches (internal streams), which therefore co-run with it.
     hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
     if (done) HIP_OK(c, hipEventRecord(done, st));
@@ -516,11 +528,27 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   return OFDG_OK;
 }
 
+// background_prep: (upload the records of n samples and) render their 2W x 2H background
+// textures into the slot's buffer on stream `s` (bgprep_kernel)
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s) {
+  const int W = c->prm.width, H = c->prm.height;
+  HIP_OK(c, sl.d_bgprep.reserve(n));
+  HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
+  if (host_records) {
+    HIP_OK(c, hipMemcpyAsync(sl.d_bgprep.p, host_records, (size_t)n * sizeof(DevBgPrep), hipMemcpyHostToDevice, s));
+    HIP_OK(c, hipStreamSynchronize(s));  // (pageable source owned by the caller's batch)
+  }
+  hipLaunchKernelGGL(bgprep_kernel, dim3((4 * W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
+                     sl.d_bgtex.p);
+  HIP_OK(c, hipGetLastError());
+  return OFDG_OK;
+}
+
 // realise on the host, stage, and copy the records of one batch into slot `sl`
 static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
                        int n_bps, hipStream_t st) {
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
-  RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h};
+  RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h, c->prm.background_prep};
   // the previous call's host->device copies must have left the staging buffer
   if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
   sl.res_samples = 0;
@@ -626,6 +654,10 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     HIP_OK(c, hipMemcpyAsync(sl.d_croptab.p, tab.data(), tab.size() * sizeof(DevCropRef), hipMemcpyHostToDevice, st));
     HIP_OK(c, hipStreamSynchronize(st));  // `tab` is a stack vector
   }
+  if (c->prm.background_prep) {
+    int rcb = prepare_backgrounds(c, sl, n_tasks, B.bgprep.data(), st);
+    if (rcb != OFDG_OK) return rcb;
+  }
   HIP_OK(c, hipEventRecord(c->stage_free, st));
   c->stage_pending = true;
   if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
@@ -688,6 +720,10 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
+  if (c->prm.background_prep) {
+    HIP_OK(c, sl.d_bgprep.reserve(n));
+    HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
+  }
   if (!sl.d_item_count) {
     HIP_OK(c, hipMalloc((void**)&sl.d_item_count, sizeof(int)));
     HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));

@@ -70,6 +70,19 @@ struct DevSample {
   int32_t n_shapes;
 };
 
+// Background texture preparation of one sample (ofdg_params.background_prep = 1):
+// Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift), DG:87-109 - the CImg chain
+// get_shift -> rotate -> crop -> resize as ONE resampling along its composed coordinate map.
+struct DevBgPrep {
+  float ca, sa;            // cos / sin of the rotation (CImg: the angle counts as degrees)
+  float w2, h2, rw2, rh2;  // centres of the pool image and of the (grown) rotated image
+  float fx, fy;            // resize step: crop columns / rows per prepared texel
+  int32_t x0, y0;          // crop origin in the rotated image
+  int32_t cw, ch;          // crop size
+  int32_t shx, shy;        // get_shift offsets
+  uint64_t image_base;     // texel offset of the pool image
+};
+
 // One served warp crop as the kernels see it (mode 9).
 struct DevCropRef {
   const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
@@ -84,6 +97,7 @@ struct RenderDims {
   int32_t n_samples;
   int32_t n_shapes;        // total rasterised shapes in the batch
   int32_t tiles_x, tiles_y;
+  int32_t bg_pitch;        // row pitch (texels) of the background textures: pool_w, or 2W when they are prepared per sample
 };
 
 }  // namespace ofdg

@@ -24,6 +24,35 @@ Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H
   return r;
 }
 
+}  // namespace
+
+// CImg 2.x: rotate() takes degrees and grows the image to round(1 + |(w-1)cos| + |(h-1)sin|);
+// crop(x0, y0, x1, y1) with float -> int truncation of x1 = x0 + 2W/zoom - 1; linear
+// get_resize with boundary 0 steps (w - 1)/(sx - 1) when enlarging, w/sx otherwise.
+DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_base) {
+  DevBgPrep p;
+  const int TW = 2 * W, TH = 2 * H;
+  const float nangle = (float)(angle - 360.0f * std::floor((double)angle / 360.0f));
+  const float rad = (float)(nangle * 3.14159265358979323846 / 180.0);
+  p.ca = std::cos(rad);
+  p.sa = std::sin(rad);
+  const float ux = std::fabs((pw - 1) * p.ca), uy = std::fabs((pw - 1) * p.sa);
+  const float vx = std::fabs((ph - 1) * p.sa), vy = std::fabs((ph - 1) * p.ca);
+  const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
+  p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
+  p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
+  p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
+  const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
+  p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  p.fx = TW > p.cw ? (float)((p.cw - 1.0) / (TW - 1.0)) : (float)((double)p.cw / TW);
+  p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
+  p.shx = shift_x; p.shy = shift_y;
+  p.image_base = image_base;
+  return p;
+}
+
+namespace {
+
 int push_shape(const RealizeConfig& cfg, const ofdg_blueprint& p, const Mat& bg_motion, int sample, int object, int obj_local, int deform,
                std::vector<DevShape>* shapes, std::string* msg) {
   if (p.obj_type != OFDG_OBJ_ELLIPSE && p.obj_type != OFDG_OBJ_POLYGON) {
@@ -74,6 +103,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
   out->objects.clear();
   out->samples.clear();
   out->crops.clear();
+  out->bgprep.clear();
   const bool mode9 = (cfg.mode == 9);
   auto serve = [&](bool background) -> int {  // returns deform = table index + 1
     out->crops.push_back(CropUse{crops->get(), background ? 1 : 0});
@@ -124,7 +154,14 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       // m_intrinsic_transform_inv * m_motion * m_intrinsic_transform (:673, 677), inverted (:203-205)
       Mat warp = mat_mul(mat_mul(intrinsic_inv, bg_motion), intrinsic);
       o.tex_inv = mat_invert(warp);
-      o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;
+      if (cfg.background_prep) {
+        // the sample's own prepared 2W x 2H texture (bgprep_kernel), in the slot's buffer
+        out->bgprep.push_back(make_bg_prep(cfg.pool_w, cfg.pool_h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y,
+                                           (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels));
+        o.tex_base = (uint64_t)t * 4ull * (uint64_t)W * (uint64_t)H;
+      } else {
+        o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;
+      }
       o.first_shape = 0;
       o.n_shapes = 0;
       if (mode9 && pb.do_warpfield_deformation) o.deform = serve(true);  // DataGenerator.cpp:1194-1202

@@ -55,6 +55,7 @@ struct RealizedBatch {
   std::vector<DevObject> objects;
   std::vector<DevSample> samples;
   std::vector<CropUse> crops;  // DevObject/DevShape.deform - 1 indexes this table
+  std::vector<DevBgPrep> bgprep;  // per sample, if RealizeConfig.background_prep
 };
 
 // CropGenerator::get_crop (WarpFields.cpp:516-538): crops are served in order, each
@@ -71,7 +72,11 @@ struct CropServer {
 struct RealizeConfig {
   int W, H, mode;
   int pool_n, pool_w, pool_h;
+  int background_prep = 0;
 };
+
+// getRandomizedCrop(2W, 2H, angle, zoom, shift) of a pool image as one coordinate map (DG:87-109).
+DevBgPrep make_bg_prep(int pool_w, int pool_h, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_base);
 
 // Returns OFDG_OK or an error code; *msg explains failures.
 int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,

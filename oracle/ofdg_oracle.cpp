@@ -54,6 +54,83 @@ std::vector<uint8_t> centre_crop(const Pool& pool, int raw_index, int cw, int ch
   return out;
 }
 
+// Texture::getRandomizedCrop(2W, 2H, angle, zoom, x_shift, y_shift) for the background
+// (DG:87-109, 1186-1192), branch "image at least 2W x 2H":
+//   get_shift(sx, sy, 0, 0, 3).rotate(angle, 1, 3).crop(w/2-W, h/2-H, w/2-W+2W/zoom-1, h/2-H+2H/zoom-1, 3)
+//   .resize(2W, 2H, -100, -100, 3)
+// CImg is not in the image and its boundary code 3 / rotate / resize details are version
+// dependent: PARITY UNPINNED.  Restated here as ONE resampling along the
+// composed coordinate chain of CImg 2.x (the reference interpolates twice - rotate, then
+// resize - and box-filters when zoom < 1; same geometry, one interpolation less of blur):
+//   resize   : source column of destination u = min(cw - 1, u * f), f = (cw - 1) / (2W - 1) when
+//              enlarging, cw / 2W otherwise                                       (CImg get_resize case 3, boundary 0)
+//   crop     : + (x0, y0) = (w/2 - W, h/2 - H) inside the ROTATED image
+//   rotate   : about the centres, the rotated image grown to round(1 + |(w-1)ca| + |(h-1)sa|) x ...;
+//              angle is taken in DEGREES although the sampler draws radians (reference quirk, DG:1656)
+//              x = w2 + xc*ca + yc*sa, y = h2 - xc*sa + yc*ca, mirrored into [0, w) x [0, h) (boundary 3)
+//   sample   : _linear_atXY (Neumann) on the SHIFTED image; a shifted texel (i, j) is pool texel
+//              (mirror(i - sx), mirror(j - sy)) (get_shift with boundary 3 = mirrored crop)
+//   store    : truncation to u8
+struct BgPrep {
+  float ca, sa, w2, h2, rw2, rh2, fx, fy;
+  int x0, y0, cw, ch, shx, shy;
+};
+inline float cimg_modf(float x, float m) { return (float)(x - m * std::floor((double)x / m)); }
+inline int cimg_modi(int x, int m) { const int r = x % m; return r < 0 ? r + m : r; }
+BgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int shx, int shy) {
+  BgPrep p;
+  const int TW = 2 * W, TH = 2 * H;
+  const float nangle = cimg_modf(angle, 360.0f);
+  const float rad = (float)(nangle * 3.14159265358979323846 / 180.0);
+  p.ca = std::cos(rad); p.sa = std::sin(rad);  // (float overloads, as in CImg)
+  const float ux = std::fabs((pw - 1) * p.ca), uy = std::fabs((pw - 1) * p.sa);
+  const float vx = std::fabs((ph - 1) * p.sa), vy = std::fabs((ph - 1) * p.ca);
+  const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
+  p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
+  p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
+  p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
+  const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
+  p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  // get_resize(.., 3) with boundary 0: step (w - 1) / (sx - 1) when enlarging, w / sx otherwise
+  p.fx = TW > p.cw ? (float)((p.cw - 1.0) / (TW - 1.0)) : (float)((double)p.cw / TW);
+  p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
+  p.shx = shx; p.shy = shy;
+  return p;
+}
+std::vector<uint8_t> prepared_background(const Pool& pool, int raw_index, int W, int H, float angle, float zoom, int shx, int shy) {
+  const int TW = 2 * W, TH = 2 * H, pw = pool.w, ph = pool.h;
+  const BgPrep p = make_bg_prep(pw, ph, W, H, angle, zoom, shx, shy);
+  const uint8_t* t = pool.tex(raw_index);
+  std::vector<uint8_t> out((size_t)3 * TW * TH);
+  const float ww = 2.0f * pw, hh = 2.0f * ph;
+  for (int v = 0; v < TH; ++v)
+    for (int u = 0; u < TW; ++u) {
+      const float cxf = std::min((float)(p.cw - 1), (float)u * p.fx), cyf = std::min((float)(p.ch - 1), (float)v * p.fy);
+      const float xc = ((float)p.x0 + cxf) - p.rw2, yc = ((float)p.y0 + cyf) - p.rh2;
+      float mx = cimg_modf((p.w2 + xc * p.ca) + yc * p.sa, ww), my = cimg_modf((p.h2 - xc * p.sa) + yc * p.ca, hh);
+      mx = mx < (float)pw ? mx : (ww - mx) - 1.0f;
+      my = my < (float)ph ? my : (hh - my) - 1.0f;
+      // _linear_atXY (Neumann)
+      const float nfx = mx <= 0 ? 0.f : (mx >= (float)(pw - 1) ? (float)(pw - 1) : mx);
+      const float nfy = my <= 0 ? 0.f : (my >= (float)(ph - 1) ? (float)(ph - 1) : my);
+      const int x = (int)nfx, y = (int)nfy;
+      const float dx = nfx - x, dy = nfy - y;
+      const int nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
+      // the four texels of the shifted image
+      auto sxm = [&](int i) { const int m = cimg_modi(i - p.shx, 2 * pw); return m < pw ? m : 2 * pw - m - 1; };
+      auto sym = [&](int j) { const int m = cimg_modi(j - p.shy, 2 * ph); return m < ph ? m : 2 * ph - m - 1; };
+      const int xa = sxm(x), xb = sxm(nx), ya = sym(y), yb = sym(ny);
+      for (int c = 0; c < 3; ++c) {
+        const uint8_t* pl = t + (size_t)c * pw * ph;
+        const float Icc = pl[(size_t)ya * pw + xa], Inc = pl[(size_t)ya * pw + xb];
+        const float Icn = pl[(size_t)yb * pw + xa], Inn = pl[(size_t)yb * pw + xb];
+        const float val = Icc + dx * (Inc - Icc + dy * (Icc + Inn - Icn - Inc)) + dy * (Icn - Icc);
+        out[((size_t)c * TH + v) * TW + u] = (uint8_t)val;
+      }
+    }
+  return out;
+}
+
 ShapeGeom geom_of(const ofdg_blueprint& p) {  // DG:1073-1117
   ShapeGeom g;
   g.type = p.obj_type;
@@ -84,6 +161,7 @@ struct Ctx {
   int W, H, mode;
   bool use_AA;
   bool faithful;  // 4 rasterisations per shape like the reference (cost model)
+  bool background_prep = false;  // Texture::getRandomizedCrop with the sampled rotation / zoom / shift (DG:1186-1192)
 };
 
 void set_intrinsic(Object& o, float alpha, float xs, float ys) {  // DG:302-310
@@ -307,7 +385,8 @@ bool process_task(const Ctx& c, const ofdg_task& task, const ofdg_blueprint* bps
     bg->id = pb.obj_id;
     bg->is_background = true;
     set_intrinsic(*bg, 0.f, W, H);  // DG:662
-    bg->tex[0] = centre_crop(pool, pb.tex_id, 2 * W, 2 * H);
+    bg->tex[0] = c.background_prep ? prepared_background(pool, pb.tex_id, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y)
+                                   : centre_crop(pool, pb.tex_id, 2 * W, 2 * H);
     set_motion(*bg, pb.rot, pb.scale, pb.trans_x, pb.trans_y);
     if (c.mode == 9 and pb.do_warpfield_deformation) {  // DG:1194-1202
       const WarpCrop* crop = warps->get_crop();
@@ -489,6 +568,7 @@ int ofdg_oracle_render(const ofdg_params* prm, const ofdg_task* tasks, int n_tas
                        float* img0, float* img1, float* flow, int n_threads) {
   (void)n_bps;
   Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
+  c.background_prep = prm->background_prep != 0;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
   if (pool_w < 2 * c.W || pool_h < 2 * c.H) return OFDG_ETEXTURES;
   const size_t n = (size_t)c.W * c.H;
@@ -521,6 +601,7 @@ int ofdg_oracle_shape_masks(const ofdg_params* prm, const ofdg_task* task, const
                             const uint8_t* pool_data, int pool_n, int pool_w, int pool_h,
                             uint8_t* masks, int max_shapes) {
   Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
+  c.background_prep = prm->background_prep != 0;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
   const size_t n = (size_t)c.W * c.H;
   std::vector<float> a(3 * n), b(3 * n), f(2 * n);
@@ -540,5 +621,14 @@ int ofdg_oracle_shape_masks(const ofdg_params* prm, const ofdg_task* task, const
 }
 
 int ofdg_oracle_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+
+// the record of the background preparation chain (test hook; same layout as ofdg_host_bg_prep)
+int ofdg_oracle_bg_prep(int pool_w, int pool_h, int width, int height, float angle, float zoom, int shift_x, int shift_y, float* f,
+                        int* i) {
+  const BgPrep p = make_bg_prep(pool_w, pool_h, width, height, angle, zoom, shift_x, shift_y);
+  f[0] = p.ca; f[1] = p.sa; f[2] = p.w2; f[3] = p.h2; f[4] = p.rw2; f[5] = p.rh2; f[6] = p.fx; f[7] = p.fy;
+  i[0] = p.x0; i[1] = p.y0; i[2] = p.cw; i[3] = p.ch; i[4] = p.shx; i[5] = p.shy;
+  return 0;
+}
 
 }  // extern "C"

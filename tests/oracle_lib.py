@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("first_level_threads", C.c_int32), ("second_level_threads", C.c_int32),
         ("num_objects", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("device", C.c_int32),
-        ("max_shapes_per_sample", C.c_int32), ("reserved", C.c_int32 * 9),
+        ("max_shapes_per_sample", C.c_int32), ("background_prep", C.c_int32), ("reserved", C.c_int32 * 8),
     ]
 
 

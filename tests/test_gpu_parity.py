@@ -438,3 +438,51 @@ def test_mode9_full_size_generated_fields(ofdg):
     g.render_resident(i0, i1, fl)
     g.synchronize()
     assert torch.equal(a1, i1)
+
+
+# ---- background texture preparation (CImg chain restated, parity unpinned) ----
+@pytest.mark.parametrize("mode,size,pool", [(5, (128, 96), (5, 256, 192)), (7, (128, 96), (3, 320, 260)), (5, (160, 100), (3, 384, 256))])
+def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool):
+    """background_prep = 1: every sample's 2W x 2H background texture is getRandomizedCrop(2W, 2H, rot, zoom,
+    shift) of its pool image (bgprep_kernel) - bit-exact against the oracle's restatement, pool images equal to
+    and larger than 2W x 2H (zoom < 1 then reads beyond the image: mirror)."""
+    W, H = size
+    p = ofdg.default_params(width=W, height=H, mode=mode, background_prep=1)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(pool[0], pool[1], pool[2], 9)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(mode, W, H).next(5)
+    got = render_gpu(ofdg, g, tasks, 5, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    e0, e1, ef = oracle.render(q, tasks, 5, bps, n, host_pool)
+    assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1)
+    assert ulp_diff(got[2], ef).max() == 0
+    # and it is not the centre crop: the preparation changes the frames
+    q.background_prep = 0
+    c0, _, _ = oracle.render(q, tasks, 5, bps, n, host_pool)
+    assert (c0 != e0).mean() > 0.02
+
+
+def test_background_prep_full_size_and_counter_sampler(ofdg, oracle):
+    """512x384 with 1024x768 pool images; ref-sampler blueprints bit-exact, then the device counter sampler
+    (device cosf/sinf in the preparation record: <= 1 LSB on a small fraction of the pixels)."""
+    W, H = 512, 384
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1, sampler=1, seed=21, num_objects=8)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(3, 1024, 768, 4)
+    host_pool = g.pool_download_all()
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    tasks, bps, n = oracle.Sampler(5, W, H, 8).next(2)
+    got = render_gpu(ofdg, g, tasks, 2, bps, n)
+    e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
+    assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1) and ulp_diff(got[2], ef).max() == 0
+    i0, i1, fl = ofdg.alloc_outputs(2, H, W)
+    g.forward_counter(7, 2, i0, i1, fl)
+    g.synchronize()
+    tasks, bps, n = g.sample_counter(7, 2)
+    e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
+    for got_t, exp in ((i0, e0), (i1, e1)):
+        d = np.abs(got_t.cpu().numpy() - exp)
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())

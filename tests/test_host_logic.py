@@ -249,3 +249,25 @@ def test_displacer_placement_equals_oracle(ofdg, oracle):
         b = ofdg.host_displacers(W, H, seed)
         assert a.shape == b.shape and np.array_equal(a, b)
     assert len(oracle.displacers(512, 384, 1)) == 63  # 9 rows x 7 columns
+
+
+def test_background_prep_record_equals_oracle(ofdg, oracle):
+    """The coordinate-map record of getRandomizedCrop(2W, 2H, rot, zoom, shift) (host logic of
+    background_prep = 1) is the oracle's, bit for bit, over the sampler's parameter ranges."""
+    import ctypes as C
+    sig = [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    fp, fo = ofdg.lib().ofdg_host_bg_prep, oracle.lib().ofdg_oracle_bg_prep
+    fp.argtypes = fo.argtypes = sig
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        W, H = int(rng.choice([64, 128, 160, 512])), int(rng.choice([48, 96, 100, 384]))
+        pw, ph = 2 * W + 4 * int(rng.integers(0, 40)), 2 * H + int(rng.integers(0, 90))
+        angle, zoom = float(rng.uniform(-np.pi, np.pi)), float(rng.uniform(0.8, 1.2))
+        sx, sy = int(rng.integers(0, 2)) * W, int(rng.integers(0, 2)) * H
+        a, b = ((C.c_float * 8)(), (C.c_int * 6)()), ((C.c_float * 8)(), (C.c_int * 6)())
+        assert fp(pw, ph, W, H, angle, zoom, sx, sy, *a) == 0
+        fo(pw, ph, W, H, angle, zoom, sx, sy, *b)
+        assert bytes(a[0]) == bytes(b[0]) and list(a[1]) == list(b[1])
+    # identity parameters: the centre crop, unit steps
+    assert fp(300, 200, 64, 48, 0.0, 1.0, 0, 0, *a) == 0
+    assert list(a[0])[:2] == [1.0, 0.0] and list(a[0])[6:] == [1.0, 1.0] and list(a[1]) == [86, 52, 128, 96, 0, 0]

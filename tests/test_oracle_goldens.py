@@ -174,3 +174,25 @@ def test_aa_byte_table(oracle):
     _, _, aa = oracle.tables()
     assert aa[0] == 0 and aa[255] == 255
     assert all(aa[c] == c - 1 for c in range(1, 255))
+
+
+def test_background_prep_identity_is_the_centre_crop(oracle):
+    """getRandomizedCrop(2W, 2H, angle 0, zoom 1, shift 0) is the centre 2W x 2H crop:
+    the restated preparation chain must reproduce the parity boundary exactly, and differ otherwise."""
+    import numpy as np
+    W, H, mode = 64, 48, 5
+    rng = np.random.default_rng(3)
+    pool = rng.integers(0, 256, size=(2, 3, 2 * H + 37, 2 * W + 50), dtype=np.uint8)
+    tasks, bps, n = oracle.Sampler(mode, W, H, 3).next(2)
+    p0 = oracle.default_params(W, H, mode, num_objects=3)
+    p1 = oracle.default_params(W, H, mode, num_objects=3)
+    p1.background_prep = 1
+    base = oracle.render(p0, tasks, 2, bps, n, pool)
+    changed = oracle.render(p1, tasks, 2, bps, n, pool)
+    assert (base[0] != changed[0]).mean() > 0.2
+    for t in tasks:
+        b = bps[t.background]
+        b.tex_rot, b.tex_scale, b.tex_shift_x, b.tex_shift_y = 0.0, 1.0, 0, 0
+    same = oracle.render(p1, tasks, 2, bps, n, pool)
+    for a, b in zip(base, same):
+        assert np.array_equal(a, b)

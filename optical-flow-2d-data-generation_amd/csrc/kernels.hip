@@ -1389,20 +1389,15 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
   if (m < 0) m += 2 * n;
   return m < n ? m : 2 * n - m - 1;
 }
-__global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, const uint32_t* __restrict__ pool,
-                                                     int pw, int ph, int W, int H, uint32_t* __restrict__ bgtex) {
-  const int TW = 2 * W, TH = 2 * H;
-  const int s = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= TW * TH) return;
-  const int u = i % TW, v = i / TW;
-  const DevBgPrep p = prep[s];
-  const uint32_t* img = pool + p.image_base;
+// one prepared texel (strict fp32, the oracle's operation order)
+__device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, int u, int v) {
   const float ww = 2.0f * pw, hh = 2.0f * ph;
   const float cxf = fminf((float)(p.cw - 1), __fmul_rn((float)u, p.fx)), cyf = fminf((float)(p.ch - 1), __fmul_rn((float)v, p.fy));
   const float xc = __fsub_rn(__fadd_rn((float)p.x0, cxf), p.rw2), yc = __fsub_rn(__fadd_rn((float)p.y0, cyf), p.rh2);
-  float mx = cimg_modf(__fadd_rn(__fadd_rn(p.w2, __fmul_rn(xc, p.ca)), __fmul_rn(yc, p.sa)), ww);
-  float my = cimg_modf(__fadd_rn(__fsub_rn(p.h2, __fmul_rn(xc, p.sa)), __fmul_rn(yc, p.ca)), hh);
+  float mx = __fadd_rn(__fadd_rn(p.w2, __fmul_rn(xc, p.ca)), __fmul_rn(yc, p.sa));
+  float my = __fadd_rn(__fsub_rn(p.h2, __fmul_rn(xc, p.sa)), __fmul_rn(yc, p.ca));
+  if (!(mx >= 0.f && mx < ww)) mx = cimg_modf(mx, ww);  // (cimg::mod is the identity on [0, m))
+  if (!(my >= 0.f && my < hh)) my = cimg_modf(my, hh);
   mx = mx < (float)pw ? mx : __fsub_rn(__fsub_rn(ww, mx), 1.0f);
   my = my < (float)ph ? my : __fsub_rn(__fsub_rn(hh, my), 1.0f);
   // _linear_atXY (Neumann) on the shifted image
@@ -1411,10 +1406,13 @@ __global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict
   const int x = (int)nfx, y = (int)nfy;
   const float dx = __fsub_rn(nfx, (float)x), dy = __fsub_rn(nfy, (float)y);
   const int nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
-  const int xa = mirror_index(x - p.shx, pw), xb = mirror_index(nx - p.shx, pw);
-  const int ya = mirror_index(y - p.shy, ph), yb = mirror_index(ny - p.shy, ph);
-  const uint32_t tcc = img[(size_t)ya * pw + xa], tnc = img[(size_t)ya * pw + xb];
-  const uint32_t tcn = img[(size_t)yb * pw + xa], tnn = img[(size_t)yb * pw + xb];
+  // texel (i, j) of the shifted image = pool texel (mirror(i - shx), mirror(j - shy)); for
+  // 0 <= shift <= size the mirror of a negative index -k is k - 1
+  auto shifted = [](int i, int sh, int n) { const int j = i - sh; return (sh >= 0 && sh <= n) ? (j < 0 ? -j - 1 : j) : mirror_index(j, n); };
+  const int xa = shifted(x, p.shx, pw), xb = shifted(nx, p.shx, pw);
+  const int ya = shifted(y, p.shy, ph), yb = shifted(ny, p.shy, ph);
+  const uint32_t ra = (uint32_t)ya * (uint32_t)pw, rb = (uint32_t)yb * (uint32_t)pw;
+  const uint32_t tcc = img[ra + xa], tnc = img[ra + xb], tcn = img[rb + xa], tnn = img[rb + xb];
   uint32_t out = 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -1426,7 +1424,26 @@ __global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict
     const float val = __fadd_rn(__fadd_rn(Icc, __fmul_rn(dx, __fadd_rn(__fsub_rn(Inc, Icc), __fmul_rn(dy, t)))), __fmul_rn(dy, __fsub_rn(Icn, Icc)));
     out |= (uint32_t)(unsigned char)val << sh;
   }
-  bgtex[(size_t)s * TW * TH + i] = out;
+  return out;
+}
+// one thread = 4 consecutive texels of a row of sample blockIdx.y's texture; texels outside the
+// sample's read region (DevBgPrep.r*) are skipped - compose never looks at them
+__global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, const uint32_t* __restrict__ pool,
+                                                     int pw, int ph, int W, int H, uint32_t* __restrict__ bgtex) {
+  const int TW = 2 * W, TH = 2 * H, quads = TW / 4;
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= quads * TH) return;
+  const int v = i / quads, u0 = (i - v * quads) * 4;
+  const DevBgPrep p = prep[s];
+  if (v < p.ry0 || v > p.ry1 || u0 + 3 < p.rx0 || u0 > p.rx1) return;
+  const uint32_t* img = pool + p.image_base;
+  uint4 o;
+  o.x = bgprep_texel(p, img, pw, ph, u0, v);
+  o.y = bgprep_texel(p, img, pw, ph, u0 + 1, v);
+  o.z = bgprep_texel(p, img, pw, ph, u0 + 2, v);
+  o.w = bgprep_texel(p, img, pw, ph, u0 + 3, v);
+  *reinterpret_cast<uint4*>(bgtex + (size_t)s * TW * TH + (size_t)v * TW + u0) = o;
 }
 
 __global__ __launch_bounds__(256) void pool_synth_kernel(uint32_t* __restrict__ pool, int n, int w, int h, uint32_t seed) {

@@ -538,7 +538,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
     HIP_OK(c, hipMemcpyAsync(sl.d_bgprep.p, host_records, (size_t)n * sizeof(DevBgPrep), hipMemcpyHostToDevice, s));
     HIP_OK(c, hipStreamSynchronize(s));  // (pageable source owned by the caller's batch)
   }
-  hipLaunchKernelGGL(bgprep_kernel, dim3((4 * W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
+  hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
                      sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
   return OFDG_OK;

@@ -81,6 +81,7 @@ struct DevBgPrep {
   int32_t cw, ch;          // crop size
   int32_t shx, shy;        // get_shift offsets
   uint64_t image_base;     // texel offset of the pool image
+  int32_t rx0, ry0, rx1, ry1;  // texels of the 2W x 2H texture compose can read (inclusive); the rest is not rendered
 };
 
 // One served warp crop as the kernels see it (mode 9).

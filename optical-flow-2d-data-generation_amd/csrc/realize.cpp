@@ -48,6 +48,7 @@ DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, in
   p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
   p.shx = shift_x; p.shy = shift_y;
   p.image_base = image_base;
+  p.rx0 = 0; p.ry0 = 0; p.rx1 = TW - 1; p.ry1 = TH - 1;
   return p;
 }
 
@@ -156,8 +157,11 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       o.tex_inv = mat_invert(warp);
       if (cfg.background_prep) {
         // the sample's own prepared 2W x 2H texture (bgprep_kernel), in the slot's buffer
-        out->bgprep.push_back(make_bg_prep(cfg.pool_w, cfg.pool_h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y,
-                                           (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels));
+        DevBgPrep bp = make_bg_prep(cfg.pool_w, cfg.pool_h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y,
+                                    (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels);
+        // (mode 9 re-samples the background through a warp field: anything may be read)
+        if (!(mode9 && pb.do_warpfield_deformation)) bg_prep_region(o.tex_inv, W, H, &bp.rx0, &bp.ry0, &bp.rx1, &bp.ry1);
+        out->bgprep.push_back(bp);
         o.tex_base = (uint64_t)t * 4ull * (uint64_t)W * (uint64_t)H;
       } else {
         o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;

@@ -77,6 +77,26 @@ struct RealizeConfig {
 
 // getRandomizedCrop(2W, 2H, angle, zoom, shift) of a pool image as one coordinate map (DG:87-109).
 DevBgPrep make_bg_prep(int pool_w, int pool_h, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_base);
+// The texels of the 2W x 2H background texture compose reads: the centre W x H window (frame 0)
+// and the window mapped through the texture warp `tex_inv` (frame 1, bilinear), with a margin;
+// the whole texture if that leaves it (reflection).
+inline void bg_prep_region(const Mat& tex_inv, int W, int H, int32_t* rx0, int32_t* ry0, int32_t* rx1, int32_t* ry1) {
+  double lox = W / 2., hix = 3 * W / 2., loy = H / 2., hiy = 3 * H / 2.;
+  const double cx[4] = {W / 2., 3 * W / 2., W / 2., 3 * W / 2.}, cy[4] = {H / 2., H / 2., 3 * H / 2., 3 * H / 2.};
+  for (int k = 0; k < 4; ++k) {
+    const double x = cx[k] * tex_inv.sx + cy[k] * tex_inv.shx + tex_inv.tx, y = cx[k] * tex_inv.shy + cy[k] * tex_inv.sy + tex_inv.ty;
+    lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy;
+  }
+  const bool finite = lox == lox && hix == hix && loy == loy && hiy == hiy && hix - lox < 1e9 && hiy - loy < 1e9;
+  const int m = 3;
+  if (!finite || lox - m < 0 || loy - m < 0 || hix + m > 2 * W - 1 || hiy + m > 2 * H - 1) {
+    *rx0 = 0; *ry0 = 0; *rx1 = 2 * W - 1; *ry1 = 2 * H - 1;
+  } else {
+    *rx0 = (int32_t)lox - m; *ry0 = (int32_t)loy - m; *rx1 = (int32_t)hix + m + 1; *ry1 = (int32_t)hiy + m + 1;
+    if (*rx1 > 2 * W - 1) *rx1 = 2 * W - 1;
+    if (*ry1 > 2 * H - 1) *ry1 = 2 * H - 1;
+  }
+}
 
 // Returns OFDG_OK or an error code; *msg explains failures.
 int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,

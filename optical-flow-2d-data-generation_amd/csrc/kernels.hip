@@ -916,11 +916,11 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
               for (int j = 0; j < 2; ++j) {
                 const int ty = t.y + j;
                 if (ty < 0 || ty >= g.th) continue;
-                const RowDDA Rj = make_row(B.tex_inv, ty, g.tw, g.nshift);
+                const RowDDA Rj = make_row<kPow2>(B.tex_inv, ty, g.tw, g.nshift);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                   const int tx = t.x + i;
-                  if (tx >= 0 && tx < g.tw) tap[2 * j + i] = sample_bilinear(tex, g, Rj, tx);
+                  if (tx >= 0 && tx < g.tw) tap[2 * j + i] = sample_bilinear<kPow2>(tex, g, Rj, tx);
                 }
               }
             }
@@ -1107,11 +1107,11 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
             for (int j = 0; j < 2; ++j) {
               const int ty = t.y + j;
               if (ty < 0 || ty >= H) continue;
-              const RowDDA Rj = make_row(O.tex_inv, ty, W, g.nshift);
+              const RowDDA Rj = make_row<kPow2>(O.tex_inv, ty, W, g.nshift);
 #pragma unroll
               for (int i = 0; i < 2; ++i) {
                 const int tx = t.x + i;
-                if (tx >= 0 && tx < W) tap[2 * j + i] = sample_bilinear(tex, g, Rj, tx);
+                if (tx >= 0 && tx < W) tap[2 * j + i] = sample_bilinear<kPow2>(tex, g, Rj, tx);
               }
             }
           }
@@ -1226,6 +1226,14 @@ __global__ __launch_bounds__(64) void compose_deform_kernel(
     const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
     const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
   compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
+}
+// Mode 9, W a power of two.
+__global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_body<true, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
 }
 
 // --------------------------------------------------------------------------

@@ -500,7 +500,11 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     done = sl.ev_composed;
   }
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
-  if (c->prm.mode == 9)
+  if (c->prm.mode == 9 && (W & (W - 1)) == 0)
+    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
+                          sl.d_item_count);
+  else if (c->prm.mode == 9)
     hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
                           sl.d_item_count);

@@ -10,6 +10,8 @@ W, H, MODE, B = 512, 384, int(os.environ.get("MODE", "5")), 32
 NOBJ = int(os.environ.get("NOBJ", "16"))
 g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=MODE, num_objects=NOBJ))
 g.pool_synthetic(1000, 1024, 768, 2024)
+if MODE == 9:
+    g.warp_generate(2, 1)
 hs = ofdg.HostSampler(MODE, W, H, NOBJ)
 st = torch.cuda.current_stream().cuda_stream
 NS = 8
@@ -33,13 +35,3 @@ print("variant=%s bgonly=%s mode=%d step=%.1f us  geom=%.1f raster=%.1f compose=
 import ctypes
 g.render_slot(0, i0, i1, fl, st); g.synchronize(st)
 print("raster items in slot 0:", ofdg.lib().ofdg_debug_item_count(g.h))
-# ---- device counter sampler path: sampling + realize + render, no host data per step
-g2 = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=MODE, num_objects=NOBJ, sampler=1, seed=5, batch_size=B))
-g2.pool_synthetic(1000, 1024, 768, 2024)
-for i in range(20): g2.forward_counter(i * B, B, i0, i1, fl, st)
-g2.synchronize(st)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(200): g2.forward_counter((20 + i) * B, B, i0, i1, fl, st)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
-g2.synchronize(st)
-print("counter-sampler forward: step=%.1f us -> %.0f samples/s" % (dt * 1e6, B / dt))

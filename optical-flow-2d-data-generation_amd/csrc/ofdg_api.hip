@@ -101,6 +101,11 @@ struct ofdg_ctx {
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
   float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
+  // counter sampler, mode 9: every crop as the kernels see it, [k] the crop itself (foreground), [n_crops + k] its
+  // 2W x 2H upscaled copy (backgrounds); built once per set of crops
+  DevCropRef* d_cs_croptab = nullptr;
+  float* d_cs_bgwarp = nullptr;
+  unsigned* d_cs_bgwarp_max = nullptr;
   CropServer crop_server;
   int rs_w = 0, rs_h = 0;          // CImg resize tables for the background crops
   int *d_rs_xi = nullptr, *d_rs_yi = nullptr;
@@ -143,6 +148,8 @@ struct ofdg_ctx {
       return OFDG_EHIP;                                                                       \
     }                                                                                         \
   } while (0)
+
+static void drop_counter_croptab(ofdg_ctx* c);
 
 extern "C" {
 
@@ -280,6 +287,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
   if (c->cs_stream) (void)hipStreamDestroy(c->cs_stream);
   if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
+  drop_counter_croptab(c);
   if (c->d_warp) (void)hipFree(c->d_warp);
   if (c->d_warp_max) (void)hipFree(c->d_warp_max);
   c->d_cs_bps.release(); c->d_cs_nobj.release();
@@ -396,13 +404,82 @@ static int reserve_blockmask(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n_samples) {
   return OFDG_OK;
 }
 
+// CImg linear resize tables (X then Y), boundary 0, upscaling branch: (W+1) x (H+1) -> 2W x 2H (DG:1197-1200)
+static int ensure_resize_tables(ofdg_ctx* c) {
+  const int W = c->prm.width, H = c->prm.height;
+  if (c->rs_w == W && c->rs_h == H) return OFDG_OK;
+  auto table = [](int w, int sx, std::vector<int>& idx, std::vector<double>& alpha) {
+    idx.resize(sx); alpha.resize(sx);
+    const double f = (sx > w) ? (sx > 1 ? (w - 1.) / (sx - 1) : 0) : (double)w / sx;
+    double curr = 0, old = 0;
+    int at = 0;
+    for (int x = 0; x < sx; ++x) {
+      alpha[x] = curr - (unsigned int)curr;
+      idx[x] = at;
+      old = curr;
+      curr = std::min(w - 1., curr + f);
+      at += (int)((unsigned int)curr - (unsigned int)old);
+    }
+  };
+  std::vector<int> xi, yi;
+  std::vector<double> xa, ya;
+  table(W + 1, 2 * W, xi, xa);
+  table(H + 1, 2 * H, yi, ya);
+  if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
+  HIP_OK(c, hipMalloc((void**)&c->d_rs_xi, xi.size() * sizeof(int)));
+  HIP_OK(c, hipMalloc((void**)&c->d_rs_xa, xa.size() * sizeof(double)));
+  HIP_OK(c, hipMalloc((void**)&c->d_rs_yi, yi.size() * sizeof(int)));
+  HIP_OK(c, hipMalloc((void**)&c->d_rs_ya, ya.size() * sizeof(double)));
+  HIP_OK(c, hipMemcpy(c->d_rs_xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(c->d_rs_xa, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(c->d_rs_yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(c->d_rs_ya, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->rs_w = W; c->rs_h = H;
+  return OFDG_OK;
+}
+
+// counter sampler, mode 9: the static crop table (see ofdg_ctx::d_cs_croptab)
+static int ensure_counter_croptab(ofdg_ctx* c) {
+  if (c->d_cs_croptab) return OFDG_OK;
+  const int n = c->crop_server.n_crops;
+  if (!c->d_warp || n < 1) { c->err = "mode 9 needs warp fields: call ofdg_warp_generate or ofdg_warp_upload first"; return OFDG_EINVAL; }
+  int rc = ensure_resize_tables(c);
+  if (rc != OFDG_OK) return rc;
+  const int W = c->prm.width, H = c->prm.height;
+  const size_t crop_floats = (size_t)4 * (W + 1) * (H + 1), bg_floats = (size_t)4 * 2 * W * 2 * H;
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, hipMalloc((void**)&c->d_cs_bgwarp, (size_t)n * bg_floats * sizeof(float)));
+  HIP_OK(c, hipMalloc((void**)&c->d_cs_bgwarp_max, (size_t)n * sizeof(unsigned)));
+  HIP_OK(c, hipMemset(c->d_cs_bgwarp_max, 0, (size_t)n * sizeof(unsigned)));
+  HIP_OK(c, hipMalloc((void**)&c->d_cs_croptab, (size_t)2 * n * sizeof(DevCropRef)));
+  std::vector<DevCropRef> tab((size_t)2 * n);
+  for (int k = 0; k < n; ++k) {
+    const float* src = c->d_warp + (size_t)k * crop_floats;
+    float* dst = c->d_cs_bgwarp + (size_t)k * bg_floats;
+    hipLaunchKernelGGL(wf_resize2_kernel, dim3((2 * W * 2 * H + 255) / 256), dim3(256), 0, 0, src, W + 1, H + 1, 2 * W, 2 * H,
+                       c->d_rs_xi, c->d_rs_xa, c->d_rs_yi, c->d_rs_ya, dst, c->d_cs_bgwarp_max + k);
+    HIP_OK(c, hipGetLastError());
+    tab[k] = DevCropRef{src, c->d_warp_max + k, W + 1, H + 1};
+    tab[(size_t)n + k] = DevCropRef{dst, c->d_cs_bgwarp_max + k, 2 * W, 2 * H};
+  }
+  HIP_OK(c, hipMemcpy(c->d_cs_croptab, tab.data(), tab.size() * sizeof(DevCropRef), hipMemcpyHostToDevice));
+  HIP_OK(c, hipDeviceSynchronize());
+  return OFDG_OK;
+}
+static void drop_counter_croptab(ofdg_ctx* c) {
+  if (c->d_cs_croptab) { (void)hipFree(c->d_cs_croptab); c->d_cs_croptab = nullptr; }
+  if (c->d_cs_bgwarp) { (void)hipFree(c->d_cs_bgwarp); c->d_cs_bgwarp = nullptr; }
+  if (c->d_cs_bgwarp_max) { (void)hipFree(c->d_cs_bgwarp_max); c->d_cs_bgwarp_max = nullptr; }
+}
+
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, hipEvent_t done = nullptr) {
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
-  CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep};
+  CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
+                  c->prm.mode == 9 ? c->crop_server.n_crops : 0};
   hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, prep ? nullptr : done, 0,
                         c->cs_mode, D, first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
@@ -457,6 +534,8 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
       HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
   }
   const int* n_shapes_dev = nullptr;
+  // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
+  const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
   if (cs_first_index >= 0) {
     if (sl.sampled_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_sampled, 0));
     sl.sampled_pending = false;
@@ -477,7 +556,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   const bool prof_prep = ev && c->profiling == 2;
   hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
-                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, sl.d_croptab.p, n_shapes_dev);
+                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab, n_shapes_dev);
   HIP_OK(c, hipGetLastError());
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
@@ -502,11 +581,11 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if (c->prm.mode == 9)
     hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_croptab.p,
+                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
@@ -608,36 +687,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
       HIP_OK(c, sl.d_bgwarp.reserve(n_bg * bg_floats));
       HIP_OK(c, sl.d_bgwarp_max.reserve(n_bg));
       HIP_OK(c, hipMemsetAsync(sl.d_bgwarp_max.p, 0, n_bg * sizeof(unsigned), st));
-      // CImg linear resize tables (X then Y), boundary 0, upscaling branch
-      if (c->rs_w != W || c->rs_h != H) {
-        auto table = [](int w, int sx, std::vector<int>& idx, std::vector<double>& alpha) {
-          idx.resize(sx); alpha.resize(sx);
-          const double f = (sx > w) ? (sx > 1 ? (w - 1.) / (sx - 1) : 0) : (double)w / sx;
-          double curr = 0, old = 0;
-          int at = 0;
-          for (int x = 0; x < sx; ++x) {
-            alpha[x] = curr - (unsigned int)curr;
-            idx[x] = at;
-            old = curr;
-            curr = std::min(w - 1., curr + f);
-            at += (int)((unsigned int)curr - (unsigned int)old);
-          }
-        };
-        std::vector<int> xi, yi;
-        std::vector<double> xa, ya;
-        table(W + 1, 2 * W, xi, xa);
-        table(H + 1, 2 * H, yi, ya);
-        if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
-        HIP_OK(c, hipMalloc((void**)&c->d_rs_xi, xi.size() * sizeof(int)));
-        HIP_OK(c, hipMalloc((void**)&c->d_rs_xa, xa.size() * sizeof(double)));
-        HIP_OK(c, hipMalloc((void**)&c->d_rs_yi, yi.size() * sizeof(int)));
-        HIP_OK(c, hipMalloc((void**)&c->d_rs_ya, ya.size() * sizeof(double)));
-        HIP_OK(c, hipMemcpy(c->d_rs_xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_OK(c, hipMemcpy(c->d_rs_xa, xa.data(), xa.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIP_OK(c, hipMemcpy(c->d_rs_yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_OK(c, hipMemcpy(c->d_rs_ya, ya.data(), ya.size() * sizeof(double), hipMemcpyHostToDevice));
-        c->rs_w = W; c->rs_h = H;
-      }
+      { int rct = ensure_resize_tables(c); if (rct != OFDG_OK) return rct; }
     }
     std::vector<DevCropRef> tab(B.crops.size());
     size_t bg_at = 0;
@@ -706,7 +756,7 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
 // size slot `sl` for n device-sampled samples: a fixed number of shape slots per sample
 // (unused ones are typed 0 and produce no outline)
 static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
-  if (c->prm.mode == 9) { c->err = "the counter sampler does not support mode 9 yet (use the ref sampler)"; return OFDG_EINVAL; }
+  if (c->prm.mode == 9) { int rcw = ensure_counter_croptab(c); if (rcw != OFDG_OK) return rcw; }
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;
@@ -779,7 +829,8 @@ int ofdg_sample_counter(ofdg_ctx* c, long long first_index, int n_samples, ofdg_
   HIP_OK(c, hipDeviceSynchronize());
   HIP_OK(c, c->d_cs_bps.reserve((size_t)n_samples * kCsBlueprintsPerSample));
   HIP_OK(c, c->d_cs_nobj.reserve(n_samples));
-  hipLaunchKernelGGL(cs_sample_kernel, dim3(n_samples * kCsGroups), dim3(64), 0, 0, c->cs_mode, first_index, n_samples, c->d_cs_bps.p,
+  hipLaunchKernelGGL(cs_sample_kernel, dim3(n_samples * kCsGroups), dim3(64), 0, 0, c->cs_mode, first_index, n_samples,
+                     c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->d_cs_bps.p,
                      c->d_cs_nobj.p);
   HIP_OK(c, hipGetLastError());
   std::vector<int> nobj(n_samples);
@@ -840,6 +891,7 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
 static int warp_alloc(ofdg_ctx* c, int n_crops) {
   const size_t crop_floats = (size_t)4 * (c->prm.width + 1) * (c->prm.height + 1);
   HIP_OK(c, hipDeviceSynchronize());
+  drop_counter_croptab(c);
   if (c->d_warp) { HIP_OK(c, hipFree(c->d_warp)); c->d_warp = nullptr; }
   if (c->d_warp_max) { HIP_OK(c, hipFree(c->d_warp_max)); c->d_warp_max = nullptr; }
   HIP_OK(c, hipMalloc((void**)&c->d_warp, (size_t)n_crops * crop_floats * sizeof(float)));

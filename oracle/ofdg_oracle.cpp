@@ -313,7 +313,7 @@ Object* realize(const Ctx& c, const ofdg_blueprint* bps, int bi, const Affine& b
   std::vector<bool> comp_modes;
   if (p.obj_type == OFDG_OBJ_COMPOSITE) {
     if (c.mode == 9 and p.do_warpfield_deformation) {  // DG:1120-1128
-      o->warp = warps->get_crop();
+      o->warp = warps->get_crop_for(p.do_warpfield_deformation);
       o->has_warp = true;
     }
     if (parent) scene.components.push_back(std::move(obj)); else scene.objects[o->id] = std::move(obj);
@@ -337,7 +337,7 @@ Object* realize(const Ctx& c, const ofdg_blueprint* bps, int bi, const Affine& b
       o->warp = parent->warp;
       o->has_warp = parent->has_warp;
     } else if (not o->has_warp) {
-      o->warp = warps->get_crop();
+      o->warp = warps->get_crop_for(p.do_warpfield_deformation);
       o->has_warp = true;
     }
   }
@@ -389,7 +389,7 @@ bool process_task(const Ctx& c, const ofdg_task& task, const ofdg_blueprint* bps
                                    : centre_crop(pool, pb.tex_id, 2 * W, 2 * H);
     set_motion(*bg, pb.rot, pb.scale, pb.trans_x, pb.trans_y);
     if (c.mode == 9 and pb.do_warpfield_deformation) {  // DG:1194-1202
-      const WarpCrop* crop = warps->get_crop();
+      const WarpCrop* crop = warps->get_crop_for(pb.do_warpfield_deformation);
       bg->own_warp.reset(new WarpCrop(upscale_warp_for_background(*crop, 2 * W, 2 * H)));
       bg->warp = bg->own_warp.get();
       bg->has_warp = true;

@@ -70,6 +70,13 @@ struct WarpSource {
     if (counter > reuse) { ++head; counter = 0; }
     return c;
   }
+  // reuse < 0: the blueprint's deformation flag names the crop (flag - 1) instead of the
+  // CropGenerator's serving order - the device counter sampler assigns crops that way
+  // (a pure function of seed and sample index; ofdg_sample_counter returns flag = 1 + crop).
+  const WarpCrop* get_crop_for(int flag) {
+    if (reuse >= 0) return get_crop();
+    return crops.empty() ? nullptr : &crops[(size_t)(flag - 1) % crops.size()];
+  }
 };
 
 // CImg<float>::resize(sx,sy,-100,-100,3) (linear, boundary 0, upscaling branch),

@@ -155,3 +155,37 @@ def test_counter_forward_is_repeatable_across_its_slot_ring(ofdg, nobj):
             ref = cur
         for a, b in zip(cur, ref):
             assert np.array_equal(a, b)
+
+
+def test_counter_sampler_mode9_matches_oracle_with_named_crops(ofdg, oracle):
+    """Mode 9 on the device sampler: the crop of a deforming object is a function of (seed, sample, object);
+    ofdg_sample_counter returns it as do_warpfield_deformation = 1 + crop, and the oracle renders with exactly
+    those crops (reuse = -1).  Same tolerance as the rigid modes (device trig in the affines), and the
+    deformations are not a no-op."""
+    import torch
+    W, H, B = 128, 96, 8
+    crops = oracle.warp_crops(W, H, seed=5)[::5][:6] * 4.0
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=9, sampler=1, seed=12))
+    g.pool_synthetic(4, 256, 192, 5)
+    g.warp_upload(crops)
+    pool = g.pool_download_all()
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    g.forward_counter(300, B, i0, i1, fl)
+    g.synchronize()
+    tasks, bps, n = g.sample_counter(300, B)
+    flags = [bps[t.background].do_warpfield_deformation for t in tasks] + \
+            [bps[t.first_object + i].do_warpfield_deformation for t in tasks for i in range(t.n_objects)]
+    assert sum(1 for f in flags if f) >= 10 and max(flags) <= len(crops) and len({f for f in flags if f}) >= 3
+    e0, e1, ef = oracle.render(oracle.default_params(W, H, 9), tasks, B, bps, n, pool, warp_crops=crops, reuse=-1)
+    g0, g1, gf = i0.cpu().numpy(), i1.cpu().numpy(), fl.cpu().numpy()
+    for got, exp in ((g0, e0), (g1, e1)):
+        d = np.abs(got - exp)
+        assert (d > 1).mean() < 1e-3 and (d > 0).mean() < 5e-3, ((d > 1).sum(), (d > 0).sum())
+    ok = np.isfinite(gf) & np.isfinite(ef)
+    assert (np.isfinite(gf) == np.isfinite(ef)).mean() > 0.999
+    assert (np.abs(gf[ok] - ef[ok]) > 1e-3).mean() < 1e-3
+    # rigid rendering of the same samples differs (frame 1 and flow)
+    for i in range(n):
+        bps[i].do_warpfield_deformation = 0
+    r0, r1, rf = oracle.render(oracle.default_params(W, H, 9), tasks, B, bps, n, pool, warp_crops=crops, reuse=-1)
+    assert (r1 != e1).mean() > 0.01

@@ -440,6 +440,44 @@ class DataGenerationLayer:
             pass
 
 
+class FlowLoader:
+    """Endless iterator of (image0, image1, flow) CUDA tensors - the role of the reference's prefetch
+    thread + blocking queue (data_generation_layer.cpp:36-56, 141-172, 266-282; data_param.prefetch).
+
+    `prefetch` output buffer sets are cycled; batch k+1 .. k+prefetch-1 are already enqueued on the GPU
+    while the consumer works on batch k, and a yielded set is only re-rendered `prefetch` iterations
+    later.  Everything is stream-ordered on `stream` (default: torch's current stream): use the tensors on
+    that stream, or synchronise before touching them elsewhere.  Samples shard over ranks by global index
+    (params.rank / params.world_size): no communication."""
+
+    def __init__(self, params=None, pool=None, prefetch=3, stream=None, **kw):
+        import torch
+        self.gen = Generator(params, **kw)
+        p = self.gen.params
+        if pool is not None:
+            pool(self.gen)                      # callable that fills the texture pool (pool_synthetic / pool_upload ...)
+        if p.mode == 9 and self.gen.warp_count() == 0:
+            self.gen.warp_generate(2, p.seed)
+        self.prefetch = max(2, int(prefetch))
+        self.stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.bufs = [alloc_outputs(p.batch_size, p.height, p.width) for _ in range(self.prefetch)]
+        self.k = 0
+        for b in self.bufs[:-1]:                # fill the ring
+            self.gen.forward(*b, self.stream)
+        self.head = self.prefetch - 1
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        out = self.bufs[self.k % self.prefetch]
+        # enqueue the batch that will be consumed prefetch-1 iterations from now into the free set
+        self.gen.forward(*self.bufs[self.head % self.prefetch], self.stream)
+        self.head += 1
+        self.k += 1
+        return out
+
+
 def _as_tensor(ptr, shape):
     """Wrap a raw device pointer as a float32 torch tensor (no ownership)."""
     import numpy as np

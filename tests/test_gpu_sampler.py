@@ -189,3 +189,23 @@ def test_counter_sampler_mode9_matches_oracle_with_named_crops(ofdg, oracle):
         bps[i].do_warpfield_deformation = 0
     r0, r1, rf = oracle.render(oracle.default_params(W, H, 9), tasks, B, bps, n, pool, warp_crops=crops, reuse=-1)
     assert (r1 != e1).mean() > 0.01
+
+
+def test_flow_loader_ring_yields_the_index_stream_in_order(ofdg):
+    """FlowLoader (prefetch ring over ofdg_forward): batch k of the iterator is the samples with global
+    indices k*B .. k*B+B-1, although up to prefetch-1 later batches are already in flight."""
+    import torch
+    W, H, B = 128, 96, 3
+    prm = ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=8, batch_size=B)
+    loader = ofdg.FlowLoader(prm, pool=lambda g: g.pool_synthetic(3, 256, 192, 2), prefetch=3)
+    got = []
+    for k, (a, b, f) in zip(range(5), loader):
+        torch.cuda.synchronize()
+        got.append((a.clone(), b.clone(), f.clone()))
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=8, batch_size=B))
+    g.pool_synthetic(3, 256, 192, 2)
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    for k in range(5):
+        g.forward_counter(k * B, B, i0, i1, fl)
+        g.synchronize()
+        assert torch.equal(got[k][0], i0) and torch.equal(got[k][1], i1) and torch.equal(got[k][2], fl)

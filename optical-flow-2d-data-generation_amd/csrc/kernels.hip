@@ -958,7 +958,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
   g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
   g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
   g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
-  g.pitch = dm.pool_w;
+  g.pitch = dm.fg_pitch;
 
   while (omask) {
     const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
@@ -1486,6 +1486,51 @@ __global__ __launch_bounds__(256) void pool_unpack_kernel(const uint32_t* __rest
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const uint32_t p = src[i];
     planar[i] = p & 255; planar[n + i] = (p >> 8) & 255; planar[2 * n + i] = (p >> 16) & 255;
+  }
+}
+
+// CImg<unsigned char>::get_resize(.., 3) along ONE axis of every image of a BGRX pool (the
+// reference resizes pool images that are smaller than the texture it needs, DG:102-106).
+// Enlarging: linear, table `at` = source index, `alpha` = weight (CImg's running double sums, built
+// on the host); value (T)((1 - a) * v1 + a * v2).  Shrinking (at == nullptr): moving average over
+// the w*s grid in float, / w, truncated.  dst images are ow x oh, src w x h.
+__global__ __launch_bounds__(256) void pool_resize_axis_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n_images,
+                                                               int w, int h, int s, int along_x, const int* __restrict__ at,
+                                                               const double* __restrict__ alpha) {
+  const int ow = along_x ? s : w, oh = along_x ? h : s;
+  const size_t per = (size_t)ow * oh, total = per * n_images;
+  const int n = along_x ? w : h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / per, r = i - img * per;
+    const int x = (int)(r % ow), y = (int)(r / ow);
+    const int k = along_x ? x : y, line = along_x ? y : x;
+    const uint32_t* sp = src + img * (size_t)w * h;
+    auto texel = [&](int j) { return along_x ? sp[(size_t)line * w + j] : sp[(size_t)j * w + line]; };
+    uint32_t out = 0;
+    if (at) {
+      const int a0 = at[k];
+      const double al = alpha[k];
+      const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
+        out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+      }
+    } else {
+      // destination k integrates [k*n, (k+1)*n) of the n*s grid; source j covers [j*s, (j+1)*s)
+      float acc[3] = {0.f, 0.f, 0.f};
+      const long long lo = (long long)k * n, hi = lo + n;
+      for (int j = (int)(lo / s); (long long)j * s < hi; ++j) {
+        const long long a = (long long)j * s, b = a + s;
+        const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
+        const uint32_t t = texel(j);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
+    }
+    dst[i] = out;
   }
 }
 

@@ -47,6 +47,12 @@ struct ofdg_ctx {
   // texture pool
   uint32_t* pool = nullptr;
   int pool_n = 0, pool_w = 0, pool_h = 0;
+  // where foreground (W x H) and background (2W x 2H) textures are read from: the pool images
+  // themselves (centre crops) or pools of resized copies when the images are smaller (DG:96-106)
+  uint32_t* pool_fg = nullptr;   // [n][H][W] if the images are smaller than W x H
+  uint32_t* pool_bg = nullptr;   // [n][2H][2W] if the images are smaller than 2W x 2H
+  TexSource fg_src{}, bg_src{};
+  bool pool_final = false;       // derived pools match the current pool contents
   // sampler
   std::unique_ptr<RefSampler> sampler;
   long long step = 0;
@@ -268,6 +274,8 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
   if (c->pool) (void)hipFree(c->pool);
+  if (c->pool_fg) (void)hipFree(c->pool_fg);
+  if (c->pool_bg) (void)hipFree(c->pool_bg);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& sl : c->slots) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
@@ -302,15 +310,8 @@ void ofdg_destroy(ofdg_ctx* c) {
 static int pool_check_dims(ofdg_ctx* c, int n, int w, int h) {
   const int W = c->prm.width, H = c->prm.height;
   if (n < 1) { c->err = "texture pool needs at least one image"; return OFDG_ETEXTURES; }
-  if (w < 2 * W || h < 2 * H) {
-    // the reference resizes smaller images (DataGenerator.cpp:104-108); not supported yet
-    c->err = "pool images must be at least 2W x 2H (the background's centre crop)";
-    return OFDG_ETEXTURES;
-  }
-  if ((w % 4) != 0 || ((w / 2 - W / 2) % 4) != 0) {
-    c->err = "pool image width and crop origin must be multiples of 4 texels (16-byte texture rows)";
-    return OFDG_ETEXTURES;
-  }
+  (void)W; (void)H;
+  if (w < 2 || h < 2) { c->err = "pool images must be at least 2 x 2"; return OFDG_ETEXTURES; }
   return OFDG_OK;
 }
 
@@ -323,6 +324,7 @@ int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
   HIP_OK(c, hipMalloc((void**)&c->pool, (size_t)n * w * h * sizeof(uint32_t)));
   HIP_OK(c, hipMemset(c->pool, 0, (size_t)n * w * h * sizeof(uint32_t)));
   c->pool_n = n; c->pool_w = w; c->pool_h = h;
+  c->pool_final = false;
   return OFDG_OK;
 }
 
@@ -332,6 +334,7 @@ int ofdg_pool_synthetic(ofdg_ctx* c, int n, int w, int h, uint32_t seed) {
   hipLaunchKernelGGL(pool_synth_kernel, dim3(256 * 8), dim3(256), 0, 0, c->pool, n, w, h, seed);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipDeviceSynchronize());
+  c->pool_final = false;
   return OFDG_OK;
 }
 
@@ -349,6 +352,7 @@ int ofdg_pool_upload(ofdg_ctx* c, int index, const uint8_t* bgr_planar, int w, i
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipDeviceSynchronize());
   HIP_OK(c, hipFree(tmp));
+  c->pool_final = false;
   return OFDG_OK;
 }
 
@@ -472,6 +476,78 @@ static void drop_counter_croptab(ofdg_ctx* c) {
   if (c->d_cs_bgwarp_max) { (void)hipFree(c->d_cs_bgwarp_max); c->d_cs_bgwarp_max = nullptr; }
 }
 
+// CImg<unsigned char>::get_resize(tw, th, -100, -100, 3) of every pool image (X pass, then Y pass, u8 in
+// between) into dst[n][th][tw]
+static int pool_resized_copy(ofdg_ctx* c, int tw, int th, uint32_t** dst) {
+  const int n = c->pool_n, w = c->pool_w, h = c->pool_h;
+  if (*dst) { HIP_OK(c, hipFree(*dst)); *dst = nullptr; }
+  HIP_OK(c, hipMalloc((void**)dst, (size_t)n * tw * th * sizeof(uint32_t)));
+  uint32_t* mid = nullptr;  // [n][h][tw]
+  HIP_OK(c, hipMalloc((void**)&mid, (size_t)n * tw * h * sizeof(uint32_t)));
+  auto pass = [&](const uint32_t* src, uint32_t* out, int sw, int sh, int s, int along_x) -> int {
+    const int len = along_x ? sw : sh;
+    int* d_at = nullptr;
+    double* d_alpha = nullptr;
+    if (s > len) {  // enlarging: CImg's running sums (boundary 0)
+      std::vector<int> at(s);
+      std::vector<double> alpha(s);
+      const double f = s > 1 ? (len - 1.) / (s - 1) : 0;
+      double curr = 0, old = 0;
+      int pos = 0;
+      for (int x = 0; x < s; ++x) {
+        alpha[x] = curr - (unsigned int)curr;
+        at[x] = pos;
+        old = curr;
+        curr = std::min(len - 1., curr + f);
+        pos += (int)((unsigned int)curr - (unsigned int)old);
+      }
+      HIP_OK(c, hipMalloc((void**)&d_at, s * sizeof(int)));
+      HIP_OK(c, hipMalloc((void**)&d_alpha, s * sizeof(double)));
+      HIP_OK(c, hipMemcpy(d_at, at.data(), s * sizeof(int), hipMemcpyHostToDevice));
+      HIP_OK(c, hipMemcpy(d_alpha, alpha.data(), s * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (s == len) {
+      HIP_OK(c, hipMemcpy(out, src, (size_t)n * sw * sh * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    } else {
+      hipLaunchKernelGGL(pool_resize_axis_kernel, dim3(2048), dim3(256), 0, 0, src, out, n, sw, sh, s, along_x, d_at, d_alpha);
+      HIP_OK(c, hipGetLastError());
+    }
+    HIP_OK(c, hipDeviceSynchronize());
+    if (d_at) { (void)hipFree(d_at); (void)hipFree(d_alpha); }
+    return OFDG_OK;
+  };
+  int rc = pass(c->pool, mid, w, h, tw, 1);
+  if (rc == OFDG_OK) rc = pass(mid, *dst, tw, h, th, 0);
+  (void)hipFree(mid);
+  return rc;
+}
+
+// after the pool contents are final: where foreground / background textures are read from
+static int finalise_pool(ofdg_ctx* c) {
+  if (c->pool_final) return OFDG_OK;
+  HIP_OK(c, hipDeviceSynchronize());
+  const int W = c->prm.width, H = c->prm.height, w = c->pool_w, h = c->pool_h;
+  const uint64_t img = (uint64_t)w * h;
+  if (c->pool_fg) { (void)hipFree(c->pool_fg); c->pool_fg = nullptr; }
+  if (c->pool_bg) { (void)hipFree(c->pool_bg); c->pool_bg = nullptr; }
+  if (w >= W && h >= H) {
+    c->fg_src = TexSource{img, (uint64_t)(h / 2 - H / 2) * w + (uint64_t)(w / 2 - W / 2), w, 0};
+  } else {
+    int rc = pool_resized_copy(c, W, H, &c->pool_fg);
+    if (rc != OFDG_OK) return rc;
+    c->fg_src = TexSource{(uint64_t)W * H, 0, W, 0};
+  }
+  if (w >= 2 * W && h >= 2 * H) {
+    c->bg_src = TexSource{img, (uint64_t)(h / 2 - H) * w + (uint64_t)(w / 2 - W), w, 0};
+  } else {
+    int rc = pool_resized_copy(c, 2 * W, 2 * H, &c->pool_bg);
+    if (rc != OFDG_OK) return rc;
+    c->bg_src = TexSource{(uint64_t)4 * W * H, 0, 2 * W, 0};
+  }
+  c->pool_final = true;
+  return OFDG_OK;
+}
+
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
@@ -479,7 +555,7 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
-                  c->prm.mode == 9 ? c->crop_server.n_crops : 0};
+                  c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin};
   hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, prep ? nullptr : done, 0,
                         c->cs_mode, D, first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
@@ -504,7 +580,8 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   dm.n_shapes = sl.res_shapes;
   dm.tiles_x = (W + kTileW - 1) / kTileW;
   dm.tiles_y = (H + kTileH - 1) / kTileH;
-  dm.bg_pitch = c->prm.background_prep ? 2 * W : c->pool_w;
+  dm.bg_pitch = c->prm.background_prep ? 2 * W : c->bg_src.pitch;
+  dm.fg_pitch = c->fg_src.pitch;
   const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
@@ -571,7 +648,8 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     if (prof_prep && c->overlap) HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
   }
   if (c->overlap) HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
-  const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : c->pool;  // (after the slot's buffers are final)
+  const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
+  const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
   hipEvent_t done = nullptr;
   if (c->overlap) {
@@ -581,21 +659,21 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if (c->prm.mode == 9)
     hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
     // makes room for the single-wave workgroups of the latency-bound preparation kernels of
     // the next batches (internal streams), which therefore co-run with it.
     hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, c->pool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
     if (done) HIP_OK(c, hipEventRecord(done, st));
@@ -631,7 +709,9 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
 static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
                        int n_bps, hipStream_t st) {
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
+  { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
   RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h, c->prm.background_prep};
+  cfg.fg_stride = c->fg_src.stride; cfg.fg_origin = c->fg_src.origin; cfg.bg_stride = c->bg_src.stride; cfg.bg_origin = c->bg_src.origin;
   // the previous call's host->device copies must have left the staging buffer
   if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
   sl.res_samples = 0;
@@ -757,6 +837,7 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
 // (unused ones are typed 0 and produce no outline)
 static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (c->prm.mode == 9) { int rcw = ensure_counter_croptab(c); if (rcw != OFDG_OK) return rcw; }
+  { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
   if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;

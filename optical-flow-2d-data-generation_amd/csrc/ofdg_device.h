@@ -84,6 +84,15 @@ struct DevBgPrep {
   int32_t rx0, ry0, rx1, ry1;  // texels of the 2W x 2H texture compose can read (inclusive); the rest is not rendered
 };
 
+// Where an object's texture lives relative to a pool pointer: image i starts at i * stride, its
+// W x H (foreground) or 2W x 2H (background) window at + origin, rows are `pitch` texels apart.
+// Pool images at least as large as the window: the centre crop of the image itself
+// (getRandomizedCrop, DG:96-101); smaller images: a pool of resized copies (DG:102-106).
+struct TexSource {
+  uint64_t stride, origin;
+  int32_t pitch, pad;
+};
+
 // One served warp crop as the kernels see it (mode 9).
 struct DevCropRef {
   const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
@@ -98,7 +107,8 @@ struct RenderDims {
   int32_t n_samples;
   int32_t n_shapes;        // total rasterised shapes in the batch
   int32_t tiles_x, tiles_y;
-  int32_t bg_pitch;        // row pitch (texels) of the background textures: pool_w, or 2W when they are prepared per sample
+  int32_t bg_pitch;        // row pitch (texels) of the background textures: pool_w, or 2W when they are prepared per sample / resized
+  int32_t fg_pitch;        // row pitch of the foreground textures: pool_w, or W when the pool images are smaller than W x H
 };
 
 }  // namespace ofdg

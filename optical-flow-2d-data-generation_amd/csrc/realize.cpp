@@ -41,9 +41,13 @@ DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, in
   const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
   p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
   p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
-  p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
-  const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
-  p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  if (pw >= TW && ph >= TH) {
+    p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
+    const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
+    p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  } else {  // smaller image: no crop, the whole rotated image is resized (DG:102-106)
+    p.x0 = 0; p.y0 = 0; p.cw = rw; p.ch = rh;
+  }
   p.fx = TW > p.cw ? (float)((p.cw - 1.0) / (TW - 1.0)) : (float)((double)p.cw / TW);
   p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
   p.shx = shift_x; p.shy = shift_y;
@@ -122,8 +126,9 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
   // (DataGenerator.cpp:87-109 via :1149-1150); bg: 2W x 2H centre crop (parity boundary:
   // tex_rot / tex_scale / tex_shift preparation is not applied).
   const uint64_t img_texels = (uint64_t)cfg.pool_w * cfg.pool_h;
-  const uint64_t fg_origin = (uint64_t)(cfg.pool_h / 2 - H / 2) * cfg.pool_w + (cfg.pool_w / 2 - W / 2);
-  const uint64_t bg_origin = (uint64_t)(cfg.pool_h / 2 - H) * cfg.pool_w + (cfg.pool_w / 2 - W);
+  const uint64_t fg_stride = cfg.fg_stride ? cfg.fg_stride : img_texels, bg_stride = cfg.bg_stride ? cfg.bg_stride : img_texels;
+  const uint64_t fg_origin = cfg.fg_stride ? cfg.fg_origin : (uint64_t)(cfg.pool_h / 2 - H / 2) * cfg.pool_w + (cfg.pool_w / 2 - W / 2);
+  const uint64_t bg_origin = cfg.bg_stride ? cfg.bg_origin : (uint64_t)(cfg.pool_h / 2 - H) * cfg.pool_w + (cfg.pool_w / 2 - W);
   for (int t = 0; t < n_tasks; ++t) {
     const ofdg_task& task = tasks[t];
     if (task.background < 0 || task.background >= n_bps || task.n_objects < 0 ||
@@ -164,7 +169,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         out->bgprep.push_back(bp);
         o.tex_base = (uint64_t)t * 4ull * (uint64_t)W * (uint64_t)H;
       } else {
-        o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels + bg_origin;
+        o.tex_base = (uint64_t)(pb.tex_id % cfg.pool_n) * bg_stride + bg_origin;
       }
       o.first_shape = 0;
       o.n_shapes = 0;
@@ -187,7 +192,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       const Motion m = object_motion(p, bg_motion, W, H);
       o.motion = m.motion;
       o.tex_inv = mat_invert(m.motion);
-      o.tex_base = (uint64_t)(p.tex_id % cfg.pool_n) * img_texels + fg_origin;
+      o.tex_base = (uint64_t)(p.tex_id % cfg.pool_n) * fg_stride + fg_origin;
       o.first_shape = (int32_t)out->shapes.size();
       if (p.obj_type == OFDG_OBJ_COMPOSITE) {
         if (p.n_components < 1 || p.n_components > kMaxComponents || p.first_component < 0 ||

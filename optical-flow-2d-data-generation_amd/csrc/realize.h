@@ -73,6 +73,8 @@ struct RealizeConfig {
   int W, H, mode;
   int pool_n, pool_w, pool_h;
   int background_prep = 0;
+  // texture sources (TexSource of the ctx); 0 stride = "centre crops of the pool images" computed from pool_w/h
+  uint64_t fg_stride = 0, fg_origin = 0, bg_stride = 0, bg_origin = 0;
 };
 
 // getRandomizedCrop(2W, 2H, angle, zoom, shift) of a pool image as one coordinate map (DG:87-109).

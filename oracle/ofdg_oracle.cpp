@@ -41,16 +41,79 @@ struct Pool {
   }
 };
 
+// CImg<unsigned char>::get_resize(sx, sy, -100, -100, 3) of one plane (CImg 2.x, recalled; PARITY
+// UNPINNED): X pass then Y pass, the intermediate image is u8 again.  Per axis: same size ->
+// copy; enlarging -> linear with step (w - 1) / (s - 1) (boundary 0), value (T)((1-a)*v1 + a*v2);
+// shrinking -> moving average (interpolation 2): every destination pixel integrates the source
+// pixels it overlaps on the w*s grid, in float, divided by w, truncated.
+std::vector<uint8_t> cimg_resize_axis_u8(const std::vector<uint8_t>& in, int w, int h, int s, bool along_x) {
+  const int n = along_x ? w : h;            // source length along the axis
+  const int ow = along_x ? s : w, oh = along_x ? h : s;
+  std::vector<uint8_t> out((size_t)ow * oh);
+  if (s == n) return in;
+  auto src = [&](int line, int k) -> uint8_t { return along_x ? in[(size_t)line * w + k] : in[(size_t)k * w + line]; };
+  auto dst = [&](int line, int k) -> uint8_t& { return along_x ? out[(size_t)line * ow + k] : out[(size_t)k * ow + line]; };
+  const int lines = along_x ? h : w;
+  if (s > n) {
+    const double f = s > 1 ? (n - 1.) / (s - 1) : 0;
+    std::vector<unsigned int> off(s);
+    std::vector<double> foff(s);
+    double curr = 0, old = 0;
+    for (int x = 0; x < s; ++x) {
+      foff[x] = curr - (unsigned int)curr;
+      old = curr;
+      curr = std::min(n - 1., curr + f);
+      off[x] = (unsigned int)curr - (unsigned int)old;
+    }
+    for (int line = 0; line < lines; ++line) {
+      int at = 0;
+      for (int x = 0; x < s; ++x) {
+        const double alpha = foff[x];
+        const uint8_t v1 = src(line, at), v2 = at < n - 1 ? src(line, at + 1) : v1;
+        dst(line, x) = (uint8_t)((1 - alpha) * v1 + alpha * v2);
+        at += (int)off[x];
+      }
+    }
+  } else {
+    std::vector<float> tmp(s);
+    for (int line = 0; line < lines; ++line) {
+      std::fill(tmp.begin(), tmp.end(), 0.f);
+      for (unsigned int a = (unsigned)n * s, b = n, c = s, si = 0, t = 0; a;) {
+        const unsigned int d = std::min(b, c);
+        a -= d; b -= d; c -= d;
+        tmp[t] += (float)src(line, si) * d;
+        if (!b) { tmp[t] /= n; ++t; b = n; }
+        if (!c) { ++si; c = s; }
+      }
+      for (int x = 0; x < s; ++x) dst(line, x) = (uint8_t)tmp[x];
+    }
+  }
+  return out;
+}
+std::vector<uint8_t> cimg_resize_u8(const uint8_t* plane, int w, int h, int sx, int sy) {
+  std::vector<uint8_t> in(plane, plane + (size_t)w * h);
+  std::vector<uint8_t> rx = cimg_resize_axis_u8(in, w, h, sx, true);
+  return cimg_resize_axis_u8(rx, sx, h, sy, false);
+}
+
 // Texture::getRandomizedCrop with default arguments (DG:87-109 called at
-// DG:1149-1150): get_shift(0,0), rotate(0), crop(w/2-W/2, h/2-H/2, +W-1, +H-1),
-// resize(W,H) -- all identities except the centre crop.
+// DG:1149-1150): get_shift(0,0), rotate(0), then - image at least cw x ch -
+// crop(w/2-cw/2, h/2-ch/2, +cw-1, +ch-1), resize(cw,ch): all identities except the centre
+// crop; - smaller image - resize(cw, ch) of the whole image.
 std::vector<uint8_t> centre_crop(const Pool& pool, int raw_index, int cw, int ch) {
   std::vector<uint8_t> out((size_t)3 * cw * ch);
   const uint8_t* t = pool.tex(raw_index);
-  const int x0 = pool.w / 2 - cw / 2, y0 = pool.h / 2 - ch / 2;
-  for (int c = 0; c < 3; ++c)
-    for (int y = 0; y < ch; ++y)
-      std::memcpy(&out[((size_t)c * ch + y) * cw], t + ((size_t)c * pool.h + (y0 + y)) * pool.w + x0, cw);
+  if (pool.w >= cw && pool.h >= ch) {
+    const int x0 = pool.w / 2 - cw / 2, y0 = pool.h / 2 - ch / 2;
+    for (int c = 0; c < 3; ++c)
+      for (int y = 0; y < ch; ++y)
+        std::memcpy(&out[((size_t)c * ch + y) * cw], t + ((size_t)c * pool.h + (y0 + y)) * pool.w + x0, cw);
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      const std::vector<uint8_t> r = cimg_resize_u8(t + (size_t)c * pool.w * pool.h, pool.w, pool.h, cw, ch);
+      std::memcpy(&out[(size_t)c * cw * ch], r.data(), r.size());
+    }
+  }
   return out;
 }
 
@@ -88,9 +151,13 @@ BgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int s
   const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
   p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
   p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
-  p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
-  const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
-  p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  if (pw >= TW && ph >= TH) {
+    p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
+    const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
+    p.cw = x1 - p.x0 + 1; p.ch = y1 - p.y0 + 1;
+  } else {  // smaller image: no crop, the whole rotated image is resized (DG:102-106)
+    p.x0 = 0; p.y0 = 0; p.cw = rw; p.ch = rh;
+  }
   // get_resize(.., 3) with boundary 0: step (w - 1) / (sx - 1) when enlarging, w / sx otherwise
   p.fx = TW > p.cw ? (float)((p.cw - 1.0) / (TW - 1.0)) : (float)((double)p.cw / TW);
   p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
@@ -570,7 +637,6 @@ int ofdg_oracle_render(const ofdg_params* prm, const ofdg_task* tasks, int n_tas
   Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
   c.background_prep = prm->background_prep != 0;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
-  if (pool_w < 2 * c.W || pool_h < 2 * c.H) return OFDG_ETEXTURES;
   const size_t n = (size_t)c.W * c.H;
   WarpSource warps(warp_crops, n_crops, c.W + 1, c.H + 1, reuse);
   int rc = OFDG_OK;

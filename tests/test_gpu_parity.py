@@ -220,8 +220,8 @@ def test_errors(ofdg):
     with pytest.raises(ofdg.OfdgError) as e:  # no texture pool yet
         g.render(tasks, 1, bps, n, i0, i1, fl)
     assert e.value.code == ofdg.ETEXTURES
-    with pytest.raises(ofdg.OfdgError) as e:  # pool images smaller than 2W x 2H
-        g.pool_synthetic(2, 128, 96, 0)
+    with pytest.raises(ofdg.OfdgError) as e:  # degenerate pool images
+        g.pool_synthetic(2, 1, 96, 0)
     assert e.value.code == ofdg.ETEXTURES
     g.pool_synthetic(2, 256, 192, 0)
     bps[tasks[0].first_object].obj_type = 0  # Dummy: "Bad object type"
@@ -486,3 +486,27 @@ def test_background_prep_full_size_and_counter_sampler(ofdg, oracle):
     for got_t, exp in ((i0, e0), (i1, e1)):
         d = np.abs(got_t.cpu().numpy() - exp)
         assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+
+
+# ---- pool images smaller than the texture they feed (the resize branch of getRandomizedCrop, DG:102-106) ----
+@pytest.mark.parametrize("pool", [(3, 200, 150), (3, 97, 61), (3, 301, 150), (2, 255, 193)],
+                         ids=["fg-crop_bg-enlarged", "fg-and-bg-enlarged", "bg-x-shrunk-y-enlarged", "odd-sizes-one-px-short"])
+@pytest.mark.parametrize("prep", [0, 1])
+def test_small_pool_images_are_resized_like_the_reference(ofdg, oracle, pool, prep):
+    """W x H = 128 x 96.  Images at least W x H give the foreground its centre crop, smaller ones are resized
+    (CImg get_resize: linear when enlarging, moving average when shrinking, per axis, u8 between the passes);
+    the background texture needs 2W x 2H = 256 x 192.  With background_prep the chain runs on the original image
+    without the crop.  Bit-exact against the oracle; any pool width works (no alignment requirement)."""
+    W, H, B = 128, 96, 4
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=prep)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(pool[0], pool[1], pool[2], 3)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = prep
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
+    assert ulp_diff(got[2], ef).max() == 0

@@ -128,6 +128,8 @@ void ofdg_default_params(ofdg_params* p);
  */
 int ofdg_create(const ofdg_params* params, ofdg_ctx** out);
 void ofdg_destroy(ofdg_ctx* ctx);
+/* The parameters the ctx was created with. */
+const ofdg_params* ofdg_ctx_params(const ofdg_ctx* ctx);
 /* Message of the last failure on this ctx (or of a failed ofdg_create if ctx==NULL). */
 const char* ofdg_last_error(const ofdg_ctx* ctx);
 
@@ -138,6 +140,11 @@ int ofdg_pool_synthetic(ofdg_ctx* ctx, int n, int w, int h, uint32_t seed);
 int ofdg_pool_alloc(ofdg_ctx* ctx, int n, int w, int h);
 /* Upload one texture: planar B,G,R u8 (CImg layout after the swap at DG:129-131). */
 int ofdg_pool_upload(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, int w, int h);
+/* A pool of n images of DIFFERENT sizes (real texture lists, TextureCollection DG:117-149): every image is
+ * reduced at upload to what the path reads - its W x H foreground texture and its 2W x 2H background texture
+ * (centre crop, or the CImg-resized whole image if it is smaller, DG:96-106).  Not with background_prep. */
+int ofdg_pool_alloc_mixed(ofdg_ctx* ctx, int n);
+int ofdg_pool_upload_mixed(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, int w, int h);
 /* Download texture `index` as planar B,G,R u8 (w*h*3 bytes). */
 int ofdg_pool_download(ofdg_ctx* ctx, int index, uint8_t* bgr_planar);
 int ofdg_pool_info(const ofdg_ctx* ctx, int* n, int* w, int* h);

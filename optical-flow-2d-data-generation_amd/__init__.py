@@ -69,7 +69,7 @@ _lib = None
 # every symbol include/ofdg.h declares
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
-    "ofdg_host_bg_prep", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
+    "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
@@ -194,6 +194,16 @@ class Generator:
         a = np.ascontiguousarray(bgr_planar, np.uint8)
         _, h, w = a.shape
         self._check(lib().ofdg_pool_upload(self.h, index, a.ctypes.data_as(C.c_void_p), w, h))
+
+    def pool_alloc_mixed(self, n):
+        """A pool of n images of different sizes (each reduced at upload to its W x H / 2W x 2H textures)."""
+        self._check(lib().ofdg_pool_alloc_mixed(self.h, n))
+
+    def pool_upload_mixed(self, index, bgr_planar):
+        import numpy as np
+        a = np.ascontiguousarray(bgr_planar, np.uint8)
+        _, h, w = a.shape
+        self._check(lib().ofdg_pool_upload_mixed(self.h, index, a.ctypes.data_as(C.c_void_p), w, h))
 
     def pool_download(self, index):
         import numpy as np

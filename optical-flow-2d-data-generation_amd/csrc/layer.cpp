@@ -213,20 +213,32 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
     paths.push_back(imagepath);
   }
   if (paths.empty()) throw std::runtime_error("Could not open texture collection (no images listed)");
+  // images of one size: the pool keeps them whole; of different sizes: every image is reduced to the two
+  // textures the path reads (ofdg_pool_alloc_mixed)
+  std::vector<std::vector<uint8_t>> first(1);
   int pw = 0, ph = 0;
+  bool mixed = false;
+  for (size_t i = 0; i < paths.size() && !mixed; ++i) {  // headers decide (cheap: the pixel data of the first image only)
+    std::ifstream f(paths[i], std::ios::binary);
+    std::string magic;
+    int w = 0, h = 0;
+    if (!f.is_open() || !(f >> magic) || magic != "P6") throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + " as binary PPM)");
+    for (int k = 0; k < 2; ++k) {
+      for (;;) { const int ch = f.peek(); if (ch == '#') { std::string line; std::getline(f, line); } else if (std::isspace(ch)) f.get(); else break; }
+      f >> (k == 0 ? w : h);
+    }
+    if (i == 0) { pw = w; ph = h; } else if (w != pw || h != ph) mixed = true;
+  }
+  const ofdg_params* prm = ofdg_ctx_params(ctx);
+  if (mixed && prm && prm->background_prep) throw std::runtime_error("Could not open texture collection (background_prep needs pool images of one size)");
+  const int rc_alloc = mixed ? ofdg_pool_alloc_mixed(ctx, (int)paths.size()) : ofdg_pool_alloc(ctx, (int)paths.size(), pw, ph);
+  if (rc_alloc != OFDG_OK) throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
   for (size_t i = 0; i < paths.size(); ++i) {
     std::vector<uint8_t> img;
     int w = 0, h = 0;
     if (!read_ppm(paths[i], &img, &w, &h)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + " as binary PPM)");
-    if (i == 0) {
-      pw = w; ph = h;
-      if (ofdg_pool_alloc(ctx, (int)paths.size(), w, h) != OFDG_OK)
-        throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
-    } else if (w != pw || h != ph) {
-      throw std::runtime_error("Could not open texture collection (all pool images must share one size)");
-    }
-    if (ofdg_pool_upload(ctx, (int)i, img.data(), w, h) != OFDG_OK)
-      throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
+    const int rc = mixed ? ofdg_pool_upload_mixed(ctx, (int)i, img.data(), w, h) : ofdg_pool_upload(ctx, (int)i, img.data(), w, h);
+    if (rc != OFDG_OK) throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
   }
 }
 

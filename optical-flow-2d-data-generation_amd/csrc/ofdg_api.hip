@@ -53,6 +53,7 @@ struct ofdg_ctx {
   uint32_t* pool_bg = nullptr;   // [n][2H][2W] if the images are smaller than 2W x 2H
   TexSource fg_src{}, bg_src{};
   bool pool_final = false;       // derived pools match the current pool contents
+  bool pool_mixed = false;       // ofdg_pool_alloc_mixed: only the derived pools exist (images of different sizes)
   // sampler
   std::unique_ptr<RefSampler> sampler;
   long long step = 0;
@@ -156,6 +157,7 @@ struct ofdg_ctx {
   } while (0)
 
 static void drop_counter_croptab(ofdg_ctx* c);
+static int texture_of_image(ofdg_ctx* c, const uint32_t* image, int w, int h, int tw, int th, uint32_t* out);
 
 extern "C" {
 
@@ -270,6 +272,8 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   return OFDG_OK;
 }
 
+const ofdg_params* ofdg_ctx_params(const ofdg_ctx* c) { return c ? &c->prm : nullptr; }
+
 void ofdg_destroy(ofdg_ctx* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
@@ -325,7 +329,58 @@ int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
   HIP_OK(c, hipMemset(c->pool, 0, (size_t)n * w * h * sizeof(uint32_t)));
   c->pool_n = n; c->pool_w = w; c->pool_h = h;
   c->pool_final = false;
+  c->pool_mixed = false;
   return OFDG_OK;
+}
+
+// A pool of n images of DIFFERENT sizes (real texture lists): only what the path reads is kept - every
+// image's W x H foreground texture and 2W x 2H background texture (centre crop, or the resized image if
+// it is smaller; DG:96-106), in two uniform arrays.  background_prep needs the originals: not available here.
+int ofdg_pool_alloc_mixed(ofdg_ctx* c, int n) {
+  if (!c) return OFDG_EINVAL;
+  if (n < 1) { c->err = "texture pool needs at least one image"; return OFDG_ETEXTURES; }
+  if (c->prm.background_prep) { c->err = "background_prep needs a pool of whole images of one size (ofdg_pool_alloc)"; return OFDG_EINVAL; }
+  const int W = c->prm.width, H = c->prm.height;
+  HIP_OK(c, hipDeviceSynchronize());
+  if (c->pool) { HIP_OK(c, hipFree(c->pool)); c->pool = nullptr; }
+  if (c->pool_fg) { HIP_OK(c, hipFree(c->pool_fg)); c->pool_fg = nullptr; }
+  if (c->pool_bg) { HIP_OK(c, hipFree(c->pool_bg)); c->pool_bg = nullptr; }
+  HIP_OK(c, hipMalloc((void**)&c->pool_fg, (size_t)n * W * H * sizeof(uint32_t)));
+  HIP_OK(c, hipMalloc((void**)&c->pool_bg, (size_t)n * 4 * W * H * sizeof(uint32_t)));
+  HIP_OK(c, hipMemset(c->pool_fg, 0, (size_t)n * W * H * sizeof(uint32_t)));
+  HIP_OK(c, hipMemset(c->pool_bg, 0, (size_t)n * 4 * W * H * sizeof(uint32_t)));
+  HIP_OK(c, hipDeviceSynchronize());
+  c->pool_n = n; c->pool_w = 0; c->pool_h = 0;
+  c->fg_src = TexSource{(uint64_t)W * H, 0, W, 0};
+  c->bg_src = TexSource{(uint64_t)4 * W * H, 0, 2 * W, 0};
+  c->pool_mixed = true;
+  c->pool_final = true;
+  return OFDG_OK;
+}
+
+// image `index` of a mixed pool: planar B,G,R u8 of any size >= 2 x 2
+int ofdg_pool_upload_mixed(ofdg_ctx* c, int index, const uint8_t* bgr_planar, int w, int h) {
+  if (!c || !bgr_planar) return OFDG_EINVAL;
+  if (!c->pool_mixed || index < 0 || index >= c->pool_n || w < 2 || h < 2) {
+    c->err = "pool_upload_mixed: no mixed pool (ofdg_pool_alloc_mixed), bad index or image smaller than 2 x 2";
+    return OFDG_ETEXTURES;
+  }
+  const int W = c->prm.width, H = c->prm.height;
+  uint8_t* tmp = nullptr;
+  uint32_t* img = nullptr;
+  const size_t n = (size_t)w * h;
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, hipMalloc((void**)&tmp, 3 * n));
+  HIP_OK(c, hipMalloc((void**)&img, n * sizeof(uint32_t)));
+  HIP_OK(c, hipMemcpy(tmp, bgr_planar, 3 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pool_pack_kernel, dim3(1024), dim3(256), 0, 0, tmp, img, w, h);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipDeviceSynchronize());
+  int rc = texture_of_image(c, img, w, h, W, H, c->pool_fg + (size_t)index * W * H);
+  if (rc == OFDG_OK) rc = texture_of_image(c, img, w, h, 2 * W, 2 * H, c->pool_bg + (size_t)index * 4 * W * H);
+  HIP_OK(c, hipDeviceSynchronize());
+  (void)hipFree(tmp); (void)hipFree(img);
+  return rc;
 }
 
 int ofdg_pool_synthetic(ofdg_ctx* c, int n, int w, int h, uint32_t seed) {
@@ -478,10 +533,7 @@ static void drop_counter_croptab(ofdg_ctx* c) {
 
 // CImg<unsigned char>::get_resize(tw, th, -100, -100, 3) of every pool image (X pass, then Y pass, u8 in
 // between) into dst[n][th][tw]
-static int pool_resized_copy(ofdg_ctx* c, int tw, int th, uint32_t** dst) {
-  const int n = c->pool_n, w = c->pool_w, h = c->pool_h;
-  if (*dst) { HIP_OK(c, hipFree(*dst)); *dst = nullptr; }
-  HIP_OK(c, hipMalloc((void**)dst, (size_t)n * tw * th * sizeof(uint32_t)));
+static int resize_images(ofdg_ctx* c, const uint32_t* images, int n, int w, int h, int tw, int th, uint32_t* out_images) {
   uint32_t* mid = nullptr;  // [n][h][tw]
   HIP_OK(c, hipMalloc((void**)&mid, (size_t)n * tw * h * sizeof(uint32_t)));
   auto pass = [&](const uint32_t* src, uint32_t* out, int sw, int sh, int s, int along_x) -> int {
@@ -516,15 +568,31 @@ static int pool_resized_copy(ofdg_ctx* c, int tw, int th, uint32_t** dst) {
     if (d_at) { (void)hipFree(d_at); (void)hipFree(d_alpha); }
     return OFDG_OK;
   };
-  int rc = pass(c->pool, mid, w, h, tw, 1);
-  if (rc == OFDG_OK) rc = pass(mid, *dst, tw, h, th, 0);
+  int rc = pass(images, mid, w, h, tw, 1);
+  if (rc == OFDG_OK) rc = pass(mid, out_images, tw, h, th, 0);
   (void)hipFree(mid);
   return rc;
+}
+static int pool_resized_copy(ofdg_ctx* c, int tw, int th, uint32_t** dst) {
+  if (*dst) { HIP_OK(c, hipFree(*dst)); *dst = nullptr; }
+  HIP_OK(c, hipMalloc((void**)dst, (size_t)c->pool_n * tw * th * sizeof(uint32_t)));
+  return resize_images(c, c->pool, c->pool_n, c->pool_w, c->pool_h, tw, th, *dst);
+}
+// the tw x th texture of ONE image of any size (getRandomizedCrop with default arguments, DG:96-106):
+// its centre crop if it is large enough, else the resized whole image
+static int texture_of_image(ofdg_ctx* c, const uint32_t* image, int w, int h, int tw, int th, uint32_t* out) {
+  if (w >= tw && h >= th) {
+    HIP_OK(c, hipMemcpy2D(out, (size_t)tw * 4, image + (size_t)(h / 2 - th / 2) * w + (w / 2 - tw / 2), (size_t)w * 4, (size_t)tw * 4, th,
+                          hipMemcpyDeviceToDevice));
+    return OFDG_OK;
+  }
+  return resize_images(c, image, 1, w, h, tw, th, out);
 }
 
 // after the pool contents are final: where foreground / background textures are read from
 static int finalise_pool(ofdg_ctx* c) {
   if (c->pool_final) return OFDG_OK;
+  if (c->pool_mixed) { c->pool_final = true; return OFDG_OK; }
   HIP_OK(c, hipDeviceSynchronize());
   const int W = c->prm.width, H = c->prm.height, w = c->pool_w, h = c->pool_h;
   const uint64_t img = (uint64_t)w * h;
@@ -708,7 +776,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
 // realise on the host, stage, and copy the records of one batch into slot `sl`
 static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
                        int n_bps, hipStream_t st) {
-  if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
+  if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
   RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h, c->prm.background_prep};
   cfg.fg_stride = c->fg_src.stride; cfg.fg_origin = c->fg_src.origin; cfg.bg_stride = c->bg_src.stride; cfg.bg_origin = c->bg_src.origin;
@@ -838,7 +906,7 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
 static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (c->prm.mode == 9) { int rcw = ensure_counter_croptab(c); if (rcw != OFDG_OK) return rcw; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
-  if (!c->pool) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
+  if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;
   const size_t shapes_cap = (size_t)n * (c->prm.mode >= 6 ? 96 : kCsMaxObjects);

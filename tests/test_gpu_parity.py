@@ -510,3 +510,63 @@ def test_small_pool_images_are_resized_like_the_reference(ofdg, oracle, pool, pr
     assert np.array_equal(got[0], e0), (got[0] != e0).mean()
     assert np.array_equal(got[1], e1), (got[1] != e1).mean()
     assert ulp_diff(got[2], ef).max() == 0
+
+
+def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle):
+    """ofdg_pool_alloc_mixed / ofdg_pool_upload_mixed (texture lists with images of different sizes): every image is
+    reduced at upload to its W x H and 2W x 2H textures.  A mixed pool holding ONE image renders exactly like the
+    uniform pool of that image (itself bit-exact against the oracle), for a large, a medium and a small image; and
+    a three-image mixed pool is consistent with them sample by sample when all of a sample's texture ids hit one image."""
+    W, H, B = 128, 96, 3
+    rng = np.random.default_rng(11)
+    images = [rng.integers(0, 256, size=(3, hh, ww), dtype=np.uint8) for ww, hh in ((301, 233), (200, 150), (90, 75))]
+    # smooth them a little so that bilinear interpolation is not just noise
+    images = [((im.astype(np.uint16) + np.roll(im, 1, axis=2) + np.roll(im, 1, axis=1) + np.roll(np.roll(im, 1, axis=1), 1, axis=2)) // 4).astype(np.uint8) for im in images]
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    prm = ofdg.default_params(width=W, height=H, mode=5)
+    for im in images:
+        gm = ofdg.Generator(prm)
+        gm.pool_alloc_mixed(1)
+        gm.pool_upload_mixed(0, im)
+        got = render_gpu(ofdg, gm, tasks, B, bps, n)
+        e0, e1, ef = oracle.render(params_for_oracle(oracle, prm), tasks, B, bps, n, im[None])
+        assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1) and ulp_diff(got[2], ef).max() == 0
+    g3 = ofdg.Generator(prm)
+    g3.pool_alloc_mixed(3)
+    for k, im in enumerate(images):
+        g3.pool_upload_mixed(k, im)
+    for k, im in enumerate(images):           # steer every texture id of the batch to image k
+        for i in range(n):
+            bps[i].tex_id = k
+        got = render_gpu(ofdg, g3, tasks, B, bps, n)
+        e0, e1, ef = oracle.render(params_for_oracle(oracle, prm), tasks, B, bps, n, im[None])
+        assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1)
+
+
+def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_path):
+    """The layer's TextureCollection loader (DG:117-149) with PPMs of three different sizes: the pool becomes a
+    mixed one; Forward() equals a Generator fed with the same images through ofdg_pool_upload_mixed."""
+    import torch
+    rng = np.random.RandomState(9)
+    paths, planar = [], []
+    for i, (ww, hh) in enumerate(((300, 220), (256, 192), (100, 64))):
+        rgb = rng.randint(0, 256, (hh, ww, 3)).astype(np.uint8)
+        p = tmp_path / ("tex%d.ppm" % i)
+        with open(p, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (ww, hh))
+            f.write(rgb.tobytes())
+        paths.append(str(p))
+        planar.append(np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))
+    lst = tmp_path / "database.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
+    a, b, f = layer.Forward()
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3))
+    g.pool_alloc_mixed(3)
+    for k, im in enumerate(planar):
+        g.pool_upload_mixed(k, im)
+    i0, i1, fl = ofdg.alloc_outputs(3, 96, 128)
+    g.forward(i0, i1, fl)
+    g.synchronize()
+    assert torch.equal(a, i0) and torch.equal(b, i1) and torch.equal(f, fl)
+    layer.close()

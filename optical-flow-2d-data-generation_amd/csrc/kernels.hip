@@ -147,13 +147,12 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
                                                    DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
                                                    unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
                                                    int* __restrict__ item_count, int4* __restrict__ items,
-                                                   const DevCropRef* __restrict__ crops,
-                                                   const int* __restrict__ n_shapes_dev) {
+                                                   const DevCropRef* __restrict__ crops) {
   __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
   __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
-  if (sf >= (n_shapes_dev ? *n_shapes_dev : n_shapes) * 2) return;  // wave-uniform
+  if (sf >= n_shapes * 2) return;  // wave-uniform
   const DevShape& S = shapes[sf >> 1];
   if (S.type == 0) return;  // unused slot of a device-sampled batch (wave-uniform)
   const Mat M = S.m[sf & 1];

@@ -655,9 +655,9 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
     ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 6];
   c->launch_count++;
-  // Preparation (geom -> bin -> raster) runs on the internal stream `ps`, compose on the
-  // caller's stream `st`.  prep(i) only waits for this slot's upload and for the compose
-  // that last read coverage workspace i % 2, so it overlaps compose(i - 1).
+  // Preparation (geom -> raster) runs on the internal stream `ps`, compose on the caller's
+  // stream `st`.  prep(i) only waits for this slot's upload / sampler and for the compose that
+  // last read coverage workspace i % 3, so it overlaps compose(i - 1) and compose(i - 2).
   const int cb = c->parity;
   c->parity = (c->parity + 1) % ofdg_ctx::kWorkspaces;
   c->last_parity = cb;
@@ -678,7 +678,6 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     else if (sl.compose_pending)
       HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
   }
-  const int* n_shapes_dev = nullptr;
   // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
   const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
   if (cs_first_index >= 0) {
@@ -701,7 +700,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   const bool prof_prep = ev && c->profiling == 2;
   hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
-                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab, n_shapes_dev);
+                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;

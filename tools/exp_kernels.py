@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer experiment: per-kernel times of the bench workload under variants
-(OFDG_VARIANT=0 fused raster / 1 coverage slots), with and without foreground objects."""
+"""Developer experiment: per-kernel times of the bench workload with host-sampled resident batches
+(MODE / NOBJ / BGONLY environment knobs)."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,8 +29,8 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
 g.set_profiling(2)
 for i in range(64): g.render_slot(i % NS, i0, i1, fl, st)
 g.synchronize(st)
-print("variant=%s bgonly=%s mode=%d step=%.1f us  geom=%.1f raster=%.1f compose=%.1f us  -> %.0f samples/s" % (
-    os.environ.get("OFDG_VARIANT", "0"), bool(os.environ.get("BGONLY")), MODE, dt * 1e6,
+print("bgonly=%s mode=%d step=%.1f us  geom=%.1f raster=%.1f compose=%.1f us  -> %.0f samples/s" % (
+    bool(os.environ.get("BGONLY")), MODE, dt * 1e6,
     g.kernel_ms("geom") * 1e3, g.kernel_ms("raster") * 1e3, g.kernel_ms("compose") * 1e3, B / dt))
 import ctypes
 g.render_slot(0, i0, i1, fl, st); g.synchronize(st)

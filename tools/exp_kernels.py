@@ -19,6 +19,12 @@ for slot in range(NS):
     tasks, bps, n = hs.next(B, cap=B * 64)
     if os.environ.get("BGONLY"):
         for t in tasks: t.n_objects = 0
+    if os.environ.get("NO_BG_DEFORM"):
+        for t in tasks: bps[t.background].do_warpfield_deformation = 0
+    if os.environ.get("NO_OBJ_DEFORM"):
+        for t in tasks:
+            for i in range(n):
+                if i != t.background: bps[i].do_warpfield_deformation = 0
     g.upload_slot(slot, tasks, B, bps, n, st)
 i0, i1, fl = ofdg.alloc_outputs(B, H, W)
 for i in range(20): g.render_slot(i % NS, i0, i1, fl, st)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
     DevShapeFrame f;
     f.n_verts = n_verts;
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
-    f.pad[0] = f.pad[1] = f.pad[2] = 0;
+    f.pad[0] = S.sample; f.pad[1] = S.obj_local; f.pad[2] = 0;  // (raster_kernel marks the block masks with these)
     frames[sf] = f;
   }
   // Raster work list: one item per 8-row band x 128-column chunk of the 64 x 8 blocks the
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
   // block against the same box.
   if (visible) {
     const int band0 = by0 / kBandRows, band1 = by1 / kBandRows;
-    {  // mark the blocks for compose
+    // Block masks: raster_kernel marks the blocks in which the outline really has coverage.  Only
+    // a deforming frame-1 outline (mode 9) is marked here, by its dilated box: its mask is
+    // re-sampled from displaced positions.
+    if ((sf & 1) && S.deform > 0) {
       const int nbx = (W + kTileW - 1) / kTileW, nby = (H + kBandRows - 1) / kBandRows;
       const int c0 = bx0 / kTileW, nc = bx1 / kTileW - c0 + 1;
       unsigned long long* m = blockmask + ((size_t)S.sample * nbx * nby) * 2 + (sf & 1);
@@ -514,7 +517,8 @@ __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShap
                                                      const int* __restrict__ item_count,
                                                      const int2* __restrict__ verts, int W, int H,
                                                      uint8_t* __restrict__ cov,
-                                                     unsigned long long* __restrict__ blockmask_next, int n_mask_words) {
+                                                     unsigned long long* __restrict__ blockmask_next, int n_mask_words,
+                                                     unsigned long long* __restrict__ blockmask) {
   __shared__ __attribute__((aligned(16))) ChunkCells s_cells[kRasterWaves];
   __shared__ int s_queue[kRasterWaves][64 * kBandRows];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -585,6 +589,7 @@ __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShap
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     // sweep: lane l owns columns 2l, 2l+1 of every row
+    int nonzero = 0;
     for (int r = 0; r < rows; ++r) {
       const int2 cv = *reinterpret_cast<const int2*>(&tc.cover[r][c2]);
       const int2 ar = *reinterpret_cast<const int2*>(&tc.area[r][c2]);
@@ -594,7 +599,17 @@ __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShap
       a0 >>= 9; a1 >>= 9;
       a0 = a0 < 0 ? -a0 : a0; a1 = a1 < 0 ? -a1 : a1;
       a0 = a0 > 255 ? 255 : a0; a1 = a1 > 255 ? 255 : a1;
-      if (in_range) *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = (uint16_t)(a0 | (a1 << 8));
+      if (in_range) { *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = (uint16_t)(a0 | (a1 << 8)); nonzero |= a0 | a1; }
+    }
+    if (blockmask) {
+      // compose visits an object in a 64 x 8 block only if its outline has coverage there: lanes 0-31 hold
+      // the left block of the chunk, lanes 32-63 the right one
+      const unsigned long long nz = __ballot(nonzero != 0);
+      const int half = lane >> 5;
+      if ((lane & 31) == 0 && ((nz >> (32 * half)) & 0xFFFFFFFFull)) {
+        const int nbx = (W + kTileW - 1) / kTileW, nby = (H + kBandRows - 1) / kBandRows;
+        atomicOr(blockmask + ((size_t)(F.pad[0] * nby + item.y) * nbx + (X0 / kTileW + half)) * 2 + (sf & 1), 1ull << F.pad[1]);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the next item's clear
   }

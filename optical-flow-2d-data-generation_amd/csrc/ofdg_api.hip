@@ -710,7 +710,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
     // hand-over event separately
     hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, prof_prep ? ev[2] : nullptr,
                           prof_prep ? ev[3] : (c->overlap ? c->ev_prep_done[cb] : nullptr), 0, sl.d_frames.p, sl.d_items.p,
-                          sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words);
+                          sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words, box_cur);
     HIP_OK(c, hipGetLastError());
     if (prof_prep && c->overlap) HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
   }
@@ -1178,7 +1178,7 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(raster_kernel, dim3(64 * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
-                     W, H, c->d_cov2[0].p, nullptr, 0);
+                     W, H, c->d_cov2[0].p, nullptr, 0, (unsigned long long*)nullptr);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipMemcpy(coverage_host, c->d_cov2[0].p, (size_t)W * H, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));

@@ -15,6 +15,8 @@ st = torch.cuda.current_stream().cuda_stream
 NS = 8
 for slot in range(NS):
     tasks, bps, n = hs.next(B, cap=B * 64)
+    if os.environ.get("BGONLY"):
+        for t in tasks: t.n_objects = 0
     g.upload_slot(slot, tasks, B, bps, n, st)
 i0, i1, fl = ofdg.alloc_outputs(B, H, W)
 for i in range(20): g.render_slot(i % NS, i0, i1, fl, st)

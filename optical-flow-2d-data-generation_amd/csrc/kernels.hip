@@ -798,8 +798,36 @@ __device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const 
 #pragma unroll
       for (int p = 0; p < kPx; ++p) out[p] = bilerp_rgb(t0[p], t1[p], (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
     } else {
+      // Some lane reflects at a texture border.  As long as every coordinate lies within one
+      // period of the image (|v| < 2 * size: always, unless the motion is absurd) the reflection
+      // is two selects per axis and all 16 taps of the lane are still in flight together;
+      // otherwise the general interpolator, pixel by pixel.
+      const int tw2 = g.tw2, th2 = g.th2;
+      bool one_period = true;
+#pragma unroll
+      for (int p = 0; p < kPx; p += kPx - 1)
+        one_period = one_period && (unsigned)((xh[p] >> 8) + tw2) < 3u * (unsigned)tw2 - 1u && (unsigned)((yh[p] >> 8) + th2) < 3u * (unsigned)th2 - 1u;
+      if (__ballot(need && !one_period) == 0ull) {
+        auto reflect = [](int v, int size, int size2) {  // wrap_mode_reflect for -size2 <= v < 2 * size2
+          int m = v < 0 ? v + size2 : v;
+          m = m >= size2 ? m - size2 : m;
+          return m >= size ? size2 - 1 - m : m;
+        };
+        uint32_t p00[kPx], p10[kPx], p01[kPx], p11[kPx];
+#pragma unroll
+        for (int p = 0; p < kPx; ++p) {
+          const int xl = need ? xh[p] >> 8 : 0, yl = need ? yh[p] >> 8 : 0;
+          const uint32_t xa = (uint32_t)reflect(xl, g.tw, tw2), xb = (uint32_t)reflect(xl + 1, g.tw, tw2);
+          const uint32_t ra = (uint32_t)reflect(yl, g.th, th2) * (uint32_t)g.pitch, rb = (uint32_t)reflect(yl + 1, g.th, th2) * (uint32_t)g.pitch;
+          p00[p] = tex[ra + xa]; p10[p] = tex[ra + xb]; p01[p] = tex[rb + xa]; p11[p] = tex[rb + xb];
+        }
+#pragma unroll
+        for (int p = 0; p < kPx; ++p)
+          out[p] = bilerp_rgb(make_uint2(p00[p], p10[p]), make_uint2(p01[p], p11[p]), (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
+      } else {
 #pragma unroll 1
-      for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear<true>(tex, g, R, i0 + p);
+        for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear<true>(tex, g, R, i0 + p);
+      }
     }
   }
 }

@@ -908,7 +908,9 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;
-  const size_t shapes_cap = (size_t)n * (c->prm.mode >= 6 ? 96 : kCsMaxObjects);
+  // outline slots per sample: the worst case, so that no sample can run out (composites have up to 7 parts)
+  const int max_objects = c->prm.num_objects > 0 ? std::min(c->prm.num_objects, kCsMaxObjects) : 24;
+  const size_t shapes_cap = (size_t)n * (size_t)(c->prm.mode >= 6 ? max_objects * 7 : max_objects);
   const size_t n_obj = (size_t)n * (1 + kCsMaxObjects);
   HIP_OK(c, sl.d_shapes.reserve(shapes_cap));
   HIP_OK(c, sl.d_frames.reserve(shapes_cap * 2));

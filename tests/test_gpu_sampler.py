@@ -209,3 +209,18 @@ def test_flow_loader_ring_yields_the_index_stream_in_order(ofdg):
         g.forward_counter(k * B, B, i0, i1, fl)
         g.synchronize()
         assert torch.equal(got[k][0], i0) and torch.equal(got[k][1], i1) and torch.equal(got[k][2], fl)
+
+
+def test_counter_sampler_has_room_for_the_worst_case_sample(ofdg):
+    """32 objects per sample in mode 7 (BASELINE config 4): up to 7 outlines per object - the device sampler's
+    per-sample outline slots must cover the worst case (no capacity error), at 1024x768."""
+    W, H, B = 1024, 768, 4
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=2, num_objects=32, batch_size=B))
+    g.pool_synthetic(3, 2048, 1536, 1)
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    for k in range(6):
+        g.forward_counter(k * B, B, i0, i1, fl)
+    g.synchronize()   # raises on a device capacity flag
+    tasks, bps, n = g.sample_counter(0, 6 * B)
+    shapes = [sum(max(1, bps[t.first_object + i].n_components) for i in range(t.n_objects)) for t in tasks]
+    assert max(shapes) > 96, "the batch should exceed the old fixed capacity"

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE configurations on one GPU (counter sampler, two output sets cycled):
+   config 3: mode 9, 512x384, batch 32, 16 objects
+   config 4: mode 7, 1024x768, 8 samples per GPU (64 over 8 GPUs), 32 objects
+   config 5: mode 7, 512x384, 32 samples per GPU (256 over 8 GPUs), pool of 10 000 x 1024x1024 textures (42 GB)"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+
+def run(name, W, H, mode, B, nobj, pool, steps=200):
+    g = ofdg.Generator(ofdg.default_params(mode=mode, batch_size=B, width=W, height=H, num_objects=nobj, sampler=1, seed=5))
+    g.pool_synthetic(*pool, 1)
+    if mode == 9:
+        g.warp_generate(2, 1)
+    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(2)]
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(20): g.forward_counter(i * B, B, *outs[i % 2], st)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(steps): g.forward_counter((20 + i) * B, B, *outs[i % 2], st)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / steps
+    g.synchronize(st)
+    px = W * H * B / dt
+    print("%s: %.1f us/step, %.0f samples/s, %.2f TB/s algorithmic (38 B/px)" % (name, dt * 1e6, B / dt, px * 38 / 1e12))
+    del g
+
+which = sys.argv[1:] or ["2", "3", "4", "5"]
+if "2" in which: run("config 2 (mode 5, 512x384, B=32, 16 obj)", 512, 384, 5, 32, 16, (1000, 1024, 768))
+if "3" in which: run("config 3 (mode 9, 512x384, B=32, 16 obj)", 512, 384, 9, 32, 16, (1000, 1024, 768))
+if "4" in which: run("config 4 (mode 7, 1024x768, B=8/GPU, 32 obj)", 1024, 768, 7, 8, 32, (250, 2048, 1536))
+if "5" in which: run("config 5 (mode 7, 512x384, B=32/GPU, 10k x 1MP pool)", 512, 384, 7, 32, 0, (10000, 1024, 1024))

@@ -233,3 +233,64 @@ def test_counter_sampler_has_room_for_the_worst_case_sample(ofdg):
     g.synchronize()   # raises on a device capacity flag
     import torch
     assert torch.isfinite(fl).all()
+
+
+def test_interleaved_entry_points_give_the_same_bytes_as_isolated_calls(ofdg):
+    """Stream/event plumbing: ofdg_render, ofdg_render_slot on several resident slots and ofdg_forward_counter
+    interleaved at random on one context (three streams, rotating coverage workspaces, sample-ahead) produce
+    exactly what each call produces on a fresh context."""
+    import torch
+    W, H, B = 128, 96, 3
+    rng = np.random.default_rng(0)
+
+    def fresh():
+        g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=4, batch_size=B))
+        g.pool_synthetic(3, 256, 192, 2)
+        return g
+
+    hs = ofdg.HostSampler(7, W, H)
+    batches = [hs.next(B, cap=B * 64) for _ in range(4)]
+
+    def isolated(kind, arg):
+        g = fresh()
+        o = ofdg.alloc_outputs(B, H, W)
+        if kind == "counter":
+            g.forward_counter(arg, B, *o)
+        else:
+            t, b, n = batches[arg]
+            g.render(t, B, b, n, *o)
+        g.synchronize()
+        return [x.clone() for x in o]
+
+    want = {("counter", i): isolated("counter", i) for i in (0, 3, 6, 9, 50)}
+    want.update({("host", k): isolated("host", k) for k in range(4)})
+    g = fresh()
+    for k in range(4):
+        t, b, n = batches[k]
+        g.upload_slot(k, t, B, b, n)
+    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(3)]
+    log = []
+    for step in range(40):
+        o = outs[step % 3]
+        r = rng.integers(0, 3)
+        if r == 0:
+            i = int(rng.choice([0, 3, 6, 9, 50]))
+            g.forward_counter(i, B, *o)
+            key = ("counter", i)
+        elif r == 1:
+            k = int(rng.integers(0, 4))
+            g.render_slot(k, *o)
+            key = ("host", k)
+        else:
+            k = int(rng.integers(0, 4))
+            t, b, n = batches[k]
+            g.render(t, B, b, n, *o)   # (re-uploads into slot 0)
+            g.upload_slot(0, *batches[0][:1], B, batches[0][1], batches[0][2])
+            key = ("host", k)
+        log.append((step % 3, key))
+        if step % 3 == 2 or step == 39:   # check the buffers written since the last check
+            g.synchronize()
+            for bi, kk in log:
+                for a, w in zip(outs[bi], want[kk]):
+                    assert torch.equal(a, w), (step, kk)
+            log = []

@@ -163,21 +163,29 @@ int ofdg_sample(ofdg_ctx* ctx, int n_tasks, ofdg_task* tasks,
  * retrieveFinishedTask (DG:1175-1254, 1308-1349) and the batch assembly of
  * load_batch (LAY:227-250).  Renders task i into slot i of the caller-owned
  * DEVICE buffers image0 [n,3,H,W], image1 [n,3,H,W], flow [n,2,H,W] (float32,
- * planar, B,G,R order, 0..255).  Asynchronous on `stream` (a hipStream_t).
+ * planar, B,G,R order, 0..255).  Asynchronous on `stream` (a hipStream_t): the
+ * call starts writing the outputs after the work enqueued on `stream` before it,
+ * and work enqueued on `stream` after it sees them.  Internally the context owns a
+ * few in-order streams ("chains", taking turns call by call) on which the record
+ * upload / device sampler, the outline, coverage and compose kernels of one call
+ * run back to back while those of the neighbouring calls overlap them; pass
+ * ofdg_stream(ctx) as `stream` to be ordered on that internal stream directly
+ * (no cross-stream wait; consecutive calls then overlap - the fast way to drive
+ * a prefetch ring: one output buffer set per call in flight).
  */
 int ofdg_render(ofdg_ctx* ctx, const ofdg_task* tasks, int n_tasks,
                 const ofdg_blueprint* bps, int n_bps,
                 float* d_image0, float* d_image1, float* d_flow, void* stream);
 
-/* Re-run the device half of the last ofdg_render (geometry already resident in
- * HBM): used to time the path with inputs resident, and for hipGraph replay. */
+/* Re-run the device half of the last render / forward call (records already
+ * resident in HBM): used to time the path with inputs resident. */
 int ofdg_render_resident(ofdg_ctx* ctx, float* d_image0, float* d_image1,
                          float* d_flow, void* stream);
 
 /* Prefetch ring (maps data_param.prefetch, LAY:36-56, 141-172): up to 16 batches can be
  * resident in HBM at once.  ofdg_upload_slot realises + uploads one batch into `slot`;
- * ofdg_render_slot renders a resident slot (any number of times).  Slot 0 is the one
- * ofdg_render / ofdg_render_resident use. */
+ * ofdg_render_slot renders a resident slot (any number of times).  ofdg_render and
+ * ofdg_forward* keep their records in private slots of their own. */
 int ofdg_upload_slot(ofdg_ctx* ctx, int slot, const ofdg_task* tasks, int n_tasks,
                      const ofdg_blueprint* bps, int n_bps, void* stream);
 int ofdg_render_slot(ofdg_ctx* ctx, int slot, float* d_image0, float* d_image1,
@@ -201,7 +209,12 @@ int ofdg_forward_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
 int ofdg_sample_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
                         ofdg_task* tasks, ofdg_blueprint* bps);
 
-/* Wait for `stream` and report device-side error flags raised by kernels. */
+/* The internal stream the NEXT render / forward call of this context will work on
+ * (a hipStream_t; they take turns).  See ofdg_render. */
+void* ofdg_stream(ofdg_ctx* ctx);
+
+/* Wait for `stream` and for everything the context has in flight, and report
+ * device-side error flags raised by kernels. */
 int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
 
 /* ---- mode 9 (non-rigid deformation) warp fields: replaces WarpFields::CropGenerator
@@ -229,7 +242,7 @@ int ofdg_debug_rasterize(ofdg_ctx* ctx, const double* xy, int n_vertices,
 int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
                         uint8_t* coverage_host);
 int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
-/* Number of raster work items the last launch of slot 0 produced (diagnostics). */
+/* Number of raster work items the last launch left unprocessed (diagnostics: 0). */
 int ofdg_debug_item_count(ofdg_ctx* ctx);
 /* Per-kernel device time (ms) of the last render, measured with HIP events on
  * the launch stream when profiling is enabled. names: "geom","raster","compose". */

@@ -70,7 +70,7 @@ _lib = None
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
-    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize",
+    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
@@ -119,6 +119,8 @@ def lib():
         L.ofdg_render_slot.argtypes = [vp, i32, vp, vp, vp, vp]
         L.ofdg_forward.argtypes = [vp, vp, vp, vp, vp]
         L.ofdg_synchronize.argtypes = [vp, vp]
+        L.ofdg_stream.argtypes = [vp]
+        L.ofdg_stream.restype = vp
         L.ofdg_debug_rasterize.argtypes = [vp, vp, i32, vp]
         L.ofdg_debug_coverage.argtypes = [vp, i32, i32, i32, vp]
         L.ofdg_debug_num_shapes.argtypes = [vp, i32]
@@ -265,6 +267,11 @@ class Generator:
 
     def synchronize(self, stream=0):
         self._check(lib().ofdg_synchronize(self.h, C.c_void_p(stream)))
+
+    def next_stream(self):
+        """The internal hipStream_t (int) the next render / forward call works on; pass it as that call's
+        `stream` to be ordered on it directly (consecutive calls then overlap, see include/ofdg.h)."""
+        return int(lib().ofdg_stream(self.h) or 0)
 
     # -- mode 9 warp fields --
     def warp_generate(self, n_fields=1, seed=0):
@@ -455,10 +462,12 @@ class FlowLoader:
     thread + blocking queue (data_generation_layer.cpp:36-56, 141-172, 266-282; data_param.prefetch).
 
     `prefetch` output buffer sets are cycled; batch k+1 .. k+prefetch-1 are already enqueued on the GPU
-    while the consumer works on batch k, and a yielded set is only re-rendered `prefetch` iterations
-    later.  Everything is stream-ordered on `stream` (default: torch's current stream): use the tensors on
-    that stream, or synchronise before touching them elsewhere.  Samples shard over ranks by global index
-    (params.rank / params.world_size): no communication."""
+    while the consumer works on batch k.  Every batch is rendered on one of the generator's internal
+    in-order streams (Generator.next_stream), so the batches in flight overlap; the hand-over is two events
+    per batch: the consumer stream (`stream`, default: torch's current stream) waits for the batch it is given,
+    and a buffer set is re-rendered only after the consumer work enqueued up to the next `next()` is done.
+    Use the tensors on the consumer stream, or synchronise before touching them elsewhere.  Samples shard
+    over ranks by global index (params.rank / params.world_size): no communication."""
 
     def __init__(self, params=None, pool=None, prefetch=3, stream=None, **kw):
         import torch
@@ -469,23 +478,42 @@ class FlowLoader:
         if p.mode == 9 and self.gen.warp_count() == 0:
             self.gen.warp_generate(2, p.seed)
         self.prefetch = max(2, int(prefetch))
-        self.stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.consumer = torch.cuda.current_stream() if stream is None else torch.cuda.ExternalStream(int(stream))
         self.bufs = [alloc_outputs(p.batch_size, p.height, p.width) for _ in range(self.prefetch)]
+        self.ready = [torch.cuda.Event() for _ in range(self.prefetch)]      # batch rendered (internal stream)
+        self.released = [None] * self.prefetch                               # consumer done with the set
         self.k = 0
-        for b in self.bufs[:-1]:                # fill the ring
-            self.gen.forward(*b, self.stream)
+        for j in range(self.prefetch - 1):      # fill the ring
+            self._enqueue(j)
         self.head = self.prefetch - 1
+
+    def _enqueue(self, j):
+        import torch
+        s = self.gen.next_stream()
+        chain = torch.cuda.ExternalStream(s)
+        if self.released[j] is not None:
+            chain.wait_event(self.released[j])
+        self.gen.forward(*self.bufs[j], s)
+        self.ready[j].record(chain)
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        out = self.bufs[self.k % self.prefetch]
-        # enqueue the batch that will be consumed prefetch-1 iterations from now into the free set
-        self.gen.forward(*self.bufs[self.head % self.prefetch], self.stream)
-        self.head += 1
+        import torch
+        j = self.k % self.prefetch
+        self.consumer.wait_event(self.ready[j])
+        # the set handed out last time is free once the consumer work enqueued so far is done: render the
+        # batch that will be consumed prefetch-1 iterations from now into it
+        f = self.head % self.prefetch
+        if f != j:
+            ev = torch.cuda.Event()
+            ev.record(self.consumer)
+            self.released[f] = ev
+            self._enqueue(f)
+            self.head += 1
         self.k += 1
-        return out
+        return self.bufs[j]
 
 
 def _as_tensor(ptr, shape):

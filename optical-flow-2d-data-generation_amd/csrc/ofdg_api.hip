@@ -77,34 +77,53 @@ struct ofdg_ctx {
     int mask_used[2] = {0, 0};  // words the last launch on each parity marked (what the next clear must cover)
     hipEvent_t ev_uploaded = nullptr;
     bool upload_pending = false;
+    hipStream_t upload_stream = nullptr;   // where the records were (last) written
     DevBuf<DevCropRef> d_croptab;      // mode 9: crops of this batch's deforming objects
     DevBuf<float> d_bgwarp;            // mode 9: upscaled (2W x 2H) background crops
     DevBuf<unsigned> d_bgwarp_max;
-    hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records
+    hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records ...
     bool compose_pending = false;
-    long long composed_seq = -1;       // its launch number
+    hipStream_t compose_stream = nullptr;  // ... and the stream it ran on
     int* d_item_count = nullptr;
     int res_samples = 0, res_shapes = 0;
-    // counter sampler: records already sampled (ahead of time) for samples cs_index..cs_index+cs_n-1
-    long long cs_index = -1;
-    int cs_n = 0;
-    hipEvent_t ev_sampled = nullptr;
-    bool sampled_pending = false;
   };
   static constexpr int kUserSlots = 16;              // ofdg_upload_slot / ofdg_render_slot
-  static constexpr int kSlots = kUserSlots + 4;     // + the counter sampler's private ring
-  Slot slots[kSlots];
-  void* h_stage = nullptr;
-  size_t h_stage_bytes = 0;
-  hipEvent_t stage_free = nullptr;
-  bool stage_pending = false;
+  Slot slots[kUserSlots];
+  // pinned staging of one batch's records on their way to the device
+  struct Stage {
+    void* h = nullptr;
+    size_t bytes = 0;
+    hipEvent_t free_ev = nullptr;
+    bool pending = false;
+  };
+  Stage user_stage;  // ofdg_upload_slot
+  // The pipeline: independent IN-ORDER chains.  One call = one chain (round robin); the chain's
+  // stream runs [record upload | counter sampler] -> geom -> raster -> compose back to back, with no
+  // cross-stream hand-over between them (an event wait in front of a kernel exposes ~15 us of
+  // dispatch latency per step; kernels of one stream follow each other without a gap).  The
+  // latency-bound preparation kernels of one chain overlap the compose kernels of the others.
+  // Each chain owns its coverage workspace, a private record slot (ofdg_render / ofdg_forward*)
+  // and its staging buffer, so chains share nothing that is written per call.
+  struct Chain {
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> cov;
+    Slot slot;
+    Stage stage;
+    hipEvent_t ev_in = nullptr;   // the caller's stream at call time (outputs may still be read there)
+  };
+  static constexpr int kMaxChains = 8;
+  Chain chains[kMaxChains];
+  int n_chains = 3;       // one hardware queue each: HIP maps streams onto GPU_MAX_HW_QUEUES (4 by default) queues
+  unsigned next_chain = 0;
+  int last_chain = 0;     // the chain and the slot the last launch used (ofdg_render_resident, debug read-back)
+  Slot* last_slot = nullptr;
+  hipStream_t last_user_st = nullptr;  // OFDG_OVERLAP=0: the caller's stream of the last launch
+  bool have_last_user_st = false;
   // device counter sampler (OFDG_SAMPLER_COUNTER)
   CsMode cs_mode;
   DevBuf<ofdg_blueprint> d_cs_bps;
   DevBuf<int> d_cs_nobj;
   long long next_index = 0;  // next global sample index of this rank's stream
-  hipStream_t cs_stream = nullptr;    // samples batch i+1 while batch i is prepared and batch i-1 composed
-  long long cs_calls = 0, cs_last_index = -1;
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
   float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
@@ -117,23 +136,6 @@ struct ofdg_ctx {
   int rs_w = 0, rs_h = 0;          // CImg resize tables for the background crops
   int *d_rs_xi = nullptr, *d_rs_yi = nullptr;
   double *d_rs_xa = nullptr, *d_rs_ya = nullptr;
-  // Coverage workspaces: three, used in rotation, so that the preparation kernels of launch
-  // i+1 (internal stream) may start as soon as compose i-2 is done and are long finished when
-  // compose i ends: the cross-stream hand-over is off the critical path.
-  static constexpr int kWorkspaces = 3;
-  DevBuf<uint8_t> d_cov2[kWorkspaces];
-  hipStream_t prep_stream = nullptr;
-  hipEvent_t ev_prep_done[kWorkspaces] = {};
-  // the compose that last read coverage workspace 0 / 1: an alias of that slot's ev_composed
-  // (one event record per launch).  Composes run in launch order on one caller stream, so
-  // waiting for the later of two composes covers the earlier.
-  hipEvent_t cov_event[kWorkspaces] = {};
-  long long cov_seq[kWorkspaces] = {-1, -1, -1};
-  long long compose_seq = 0;
-  hipStream_t last_st = nullptr;
-  bool have_last_st = false;
-  int parity = 0;       // workspace of the next launch
-  int last_parity = 0;  // workspace the last launch used (debug read-back)
   bool overlap = true;
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
@@ -240,25 +242,21 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
       (e = hipMemcpy(c->d_cs_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMalloc((void**)&c->d_err, sizeof(uint32_t))) != hipSuccess ||
       (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
-      (e = hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming)) != hipSuccess) {
+      (e = hipEventCreateWithFlags(&c->user_stage.free_ev, hipEventDisableTiming)) != hipSuccess) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  // the preparation kernels are tiny and on the critical path of the next compose: give
-  // their stream the highest priority so that their workgroups are dispatched first
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if ((e = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
-      (e = hipStreamCreateWithPriority(&c->cs_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
-    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-    return OFDG_EHIP;
-  }
-  for (int i = 0; i < ofdg_ctx::kWorkspaces; ++i)
-    if ((e = hipEventCreateWithFlags(&c->ev_prep_done[i], hipEventDisableTiming)) != hipSuccess) {
-      g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
+  if (const char* v = std::getenv("OFDG_OVERLAP")) c->overlap = std::atoi(v) != 0;  // 0: everything on the caller's stream
+  if (const char* v = std::getenv("OFDG_CHAINS")) c->n_chains = std::min(std::max(std::atoi(v), 1), (int)ofdg_ctx::kMaxChains);
+  for (int i = 0; i < c->n_chains; ++i) {
+    ofdg_ctx::Chain& ch = c->chains[i];
+    if ((e = hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ch.stage.free_ev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ch.ev_in, hipEventDisableTiming)) != hipSuccess) {
+      g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
       return OFDG_EHIP;
     }
-  if (const char* v = std::getenv("OFDG_OVERLAP")) c->overlap = std::atoi(v) != 0;
+  }
   // fail early (and loudly) if the gfx950 code object is not usable on this device
   {
     hipFuncAttributes fa;
@@ -280,24 +278,27 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->pool) (void)hipFree(c->pool);
   if (c->pool_fg) (void)hipFree(c->pool_fg);
   if (c->pool_bg) (void)hipFree(c->pool_bg);
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
-  for (auto& sl : c->slots) {
+  auto drop_slot = [](ofdg_ctx::Slot& sl) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
-  }
-  for (int i = 0; i < ofdg_ctx::kWorkspaces; ++i) {
-    c->d_cov2[i].release();
-    if (c->ev_prep_done[i]) (void)hipEventDestroy(c->ev_prep_done[i]);
-  }
-  for (auto& sl : c->slots) {
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
     if (sl.ev_composed) (void)hipEventDestroy(sl.ev_composed);
-    if (sl.ev_sampled) (void)hipEventDestroy(sl.ev_sampled);
+  };
+  auto drop_stage = [](ofdg_ctx::Stage& g) {
+    if (g.h) (void)hipHostFree(g.h);
+    if (g.free_ev) (void)hipEventDestroy(g.free_ev);
+  };
+  for (auto& sl : c->slots) drop_slot(sl);
+  drop_stage(c->user_stage);
+  for (auto& ch : c->chains) {
+    drop_slot(ch.slot);
+    drop_stage(ch.stage);
+    ch.cov.release();
+    if (ch.ev_in) (void)hipEventDestroy(ch.ev_in);
+    if (ch.stream) (void)hipStreamDestroy(ch.stream);
   }
-  if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
-  if (c->cs_stream) (void)hipStreamDestroy(c->cs_stream);
   if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
   drop_counter_croptab(c);
   if (c->d_warp) (void)hipFree(c->d_warp);
@@ -305,7 +306,6 @@ void ofdg_destroy(ofdg_ctx* c) {
   c->d_cs_bps.release(); c->d_cs_nobj.release();
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
-  if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
 }
@@ -619,26 +619,35 @@ static int finalise_pool(ofdg_ctx* c) {
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
-static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, hipEvent_t done = nullptr) {
+static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
                   c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin};
-  hipExtLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, nullptr, prep ? nullptr : done, 0,
-                        c->cs_mode, D, first_index, sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
+  hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
+                     sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
   if (prep) {
     int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s);
     if (rc != OFDG_OK) return rc;
-    if (done) HIP_OK(c, hipEventRecord(done, s));
   }
-  sl.cs_index = first_index;
-  sl.cs_n = sl.res_samples;
   return OFDG_OK;
 }
 
-static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow, hipStream_t st,
-                           long long cs_first_index = -1) {
+static ofdg_ctx::Chain& take_chain(ofdg_ctx* c) {
+  const int k = (int)(c->next_chain % (unsigned)c->n_chains);
+  c->next_chain++;
+  c->last_chain = k;
+  return c->chains[k];
+}
+// the stream chain `ch` works on for a call made with the caller's stream `st`
+static hipStream_t chain_stream(const ofdg_ctx* c, const ofdg_ctx::Chain& ch, hipStream_t st) { return c->overlap ? ch.stream : st; }
+
+// [counter sampler ->] geom -> raster -> compose of the batch resident in `sl`, in order on chain `ch`.
+// `st` is the caller's stream: if it is not the chain's own stream (ofdg_stream), compose additionally waits
+// for what the caller enqueued before the call (the outputs may still be read there) and `st` waits for compose.
+static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow,
+                           hipStream_t st, long long cs_first_index = -1) {
   const int W = c->prm.width, H = c->prm.height;
   const int n_sf = sl.res_shapes * 2;
   RenderDims dm;
@@ -655,40 +664,30 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
     ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 6];
   c->launch_count++;
-  // Preparation (geom -> raster) runs on the internal stream `ps`, compose on the caller's
-  // stream `st`.  prep(i) only waits for this slot's upload / sampler and for the compose that
-  // last read coverage workspace i % 3, so it overlaps compose(i - 1) and compose(i - 2).
-  const int cb = c->parity;
-  c->parity = (c->parity + 1) % ofdg_ctx::kWorkspaces;
-  c->last_parity = cb;
-  hipStream_t ps = c->overlap ? c->prep_stream : st;
-  uint8_t* cov = c->d_cov2[cb].p;
-  if (c->overlap) {
-    if (sl.upload_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_uploaded, 0));
-    if (c->have_last_st && c->last_st != st) {
-      // the caller switched streams: composes are no longer ordered among themselves
-      HIP_OK(c, hipDeviceSynchronize());
-      for (auto& s2 : c->slots) s2.compose_pending = false;
-      for (auto& e2 : c->cov_event) e2 = nullptr;
-    }
-    c->last_st = st; c->have_last_st = true;
-    // this slot's records and coverage workspace `cb` are free once their last readers are done
-    if (c->cov_event[cb] && (!sl.compose_pending || c->cov_seq[cb] >= sl.composed_seq))
-      HIP_OK(c, hipStreamWaitEvent(ps, c->cov_event[cb], 0));
-    else if (sl.compose_pending)
-      HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_composed, 0));
+  c->last_slot = &sl;
+  if (!c->overlap) {
+    // everything runs on the caller's stream; a caller that switches streams loses the ordering
+    if (c->have_last_user_st && c->last_user_st != st) HIP_OK(c, hipDeviceSynchronize());
+    c->last_user_st = st; c->have_last_user_st = true;
+  }
+  hipStream_t S = chain_stream(c, ch, st);
+  const bool foreign = S != st;  // the caller's stream is not the chain's
+  uint8_t* cov = ch.cov.p;
+  // the slot's records: written on another stream, or still read by a compose of another chain
+  // (a user slot rendered again; the chain's private slot only ever sees its own stream)
+  if (sl.upload_pending && sl.upload_stream != S) {
+    if (hipEventQuery(sl.ev_uploaded) == hipSuccess) sl.upload_pending = false;
+    else HIP_OK(c, hipStreamWaitEvent(S, sl.ev_uploaded, 0));
+  }
+  if (sl.compose_pending && sl.compose_stream != S) {
+    if (hipEventQuery(sl.ev_composed) == hipSuccess) sl.compose_pending = false;
+    else HIP_OK(c, hipStreamWaitEvent(S, sl.ev_composed, 0));
   }
   // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
   const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
-  if (cs_first_index >= 0) {
-    if (sl.sampled_pending) HIP_OK(c, hipStreamWaitEvent(ps, sl.ev_sampled, 0));
-    sl.sampled_pending = false;
-    if (sl.cs_index != cs_first_index || sl.cs_n != sl.res_samples) {
-      // not sampled ahead of time: device counter sampler + device realize now
-      int rc = launch_counter_sampler(c, sl, cs_first_index, ps);
-      if (rc != OFDG_OK) return rc;
-    }
-    sl.cs_index = -1;  // consumed
+  if (cs_first_index >= 0) {  // device counter sampler + device realize
+    int rc = launch_counter_sampler(c, sl, cs_first_index, S);
+    if (rc != OFDG_OK) return rc;
   }
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
@@ -698,61 +697,57 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Slot& sl, float* d_img0, float
   sl.mask_used[bp] = sl.res_samples * dm.tiles_x * ((H + kBandRows - 1) / kBandRows) * 2;
   const int n_mask_words = sl.mask_used[bp ^ 1];
   const bool prof_prep = ev && c->profiling == 2;
-  hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, ps,
+  // (profiled launches: start/stop events ride on the kernels' own dispatch packets)
+  hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, S,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
                         sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
-    // (completion events ride on the kernels' own dispatch packets: no marker packets
-    // between the kernels of a stream)
-    // a profiled launch times the kernel itself (start/stop on its packet) and records the
-    // hand-over event separately
-    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, ps, prof_prep ? ev[2] : nullptr,
-                          prof_prep ? ev[3] : (c->overlap ? c->ev_prep_done[cb] : nullptr), 0, sl.d_frames.p, sl.d_items.p,
-                          sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words, box_cur);
+    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, prof_prep ? ev[2] : nullptr,
+                          prof_prep ? ev[3] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
+                          box_next, n_mask_words, box_cur);
     HIP_OK(c, hipGetLastError());
-    if (prof_prep && c->overlap) HIP_OK(c, hipEventRecord(c->ev_prep_done[cb], ps));
   }
-  if (c->overlap) HIP_OK(c, hipStreamWaitEvent(st, c->ev_prep_done[cb], 0));
   const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
   const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
+  if (foreign) {
+    HIP_OK(c, hipEventRecord(ch.ev_in, st));
+    HIP_OK(c, hipStreamWaitEvent(S, ch.ev_in, 0));
+  }
+  // completion event of compose: for the caller's stream, and for whoever touches this slot from another stream
+  const bool shared_slot = &sl != &ch.slot;
   hipEvent_t done = nullptr;
-  if (c->overlap) {
+  if (foreign || shared_slot) {
     if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
     done = sl.ev_composed;
   }
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if (c->prm.mode == 9)
-    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
     // makes room for the single-wave workgroups of the latency-bound preparation kernels of
-    // the next batches (internal streams), which therefore co-run with it.
-    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, st, k_start, k_stop, 0, dm, sl.d_samples.p,
+    // the other chains, which therefore co-run with it.
+    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
-    if (done) HIP_OK(c, hipEventRecord(done, st));
+    if (done) HIP_OK(c, hipEventRecord(done, S));
     c->ev_count++;
   }
-  if (c->overlap) {
-    sl.compose_pending = true;
-    sl.composed_seq = c->compose_seq;
-    c->cov_event[cb] = sl.ev_composed;
-    c->cov_seq[cb] = c->compose_seq;
-    c->compose_seq++;
-  }
+  if (done) { sl.compose_pending = true; sl.compose_stream = S; }
+  if (foreign) HIP_OK(c, hipStreamWaitEvent(st, done, 0));
   return OFDG_OK;
 }
 
@@ -774,13 +769,18 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
 
 // realise on the host, stage, and copy the records of one batch into slot `sl`
 static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
-                       int n_bps, hipStream_t st) {
+                       int n_bps, hipStream_t st, ofdg_ctx::Stage& stage) {
   if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
   RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h, c->prm.background_prep};
   cfg.fg_stride = c->fg_src.stride; cfg.fg_origin = c->fg_src.origin; cfg.bg_stride = c->bg_src.stride; cfg.bg_origin = c->bg_src.origin;
-  // the previous call's host->device copies must have left the staging buffer
-  if (c->stage_pending) { HIP_OK(c, hipEventSynchronize(c->stage_free)); c->stage_pending = false; }
+  // the previous copies out of this staging buffer must have left it
+  if (stage.pending) { HIP_OK(c, hipEventSynchronize(stage.free_ev)); stage.pending = false; }
+  // a compose on another stream may still read the records this upload replaces
+  if (sl.compose_pending && sl.compose_stream != st) {
+    HIP_OK(c, hipStreamWaitEvent(st, sl.ev_composed, 0));
+    sl.compose_pending = false;
+  }
   sl.res_samples = 0;
   int rc = realize_batch(cfg, tasks, n_tasks, bps, n_bps, &sl.batch, &c->err, &c->crop_server);
   if (rc != OFDG_OK) return rc;
@@ -792,9 +792,9 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   {
     const int W = c->prm.width, H = c->prm.height;
     const size_t need_cov = n_shapes * 2 * (size_t)W * H + 16;
-    if (need_cov > c->d_cov2[0].cap) {
+    if (need_cov > c->chains[0].cov.cap) {
       HIP_OK(c, hipDeviceSynchronize());
-      for (auto& ws : c->d_cov2) HIP_OK(c, ws.reserve(need_cov));
+      for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, c->chains[k].cov.reserve(need_cov));
     }
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
     (void)tiles;
@@ -811,13 +811,13 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   const size_t b_shapes = n_shapes * sizeof(DevShape), b_obj = n_obj * sizeof(DevObject),
                b_smp = (size_t)n_tasks * sizeof(DevSample);
   const size_t need = b_shapes + b_obj + b_smp + 64;
-  if (need > c->h_stage_bytes) {
-    if (c->h_stage) HIP_OK(c, hipHostFree(c->h_stage));
-    c->h_stage = nullptr;
-    HIP_OK(c, hipHostMalloc(&c->h_stage, need * 2, hipHostMallocDefault));
-    c->h_stage_bytes = need * 2;
+  if (need > stage.bytes) {
+    if (stage.h) HIP_OK(c, hipHostFree(stage.h));
+    stage.h = nullptr;
+    HIP_OK(c, hipHostMalloc(&stage.h, need * 2, hipHostMallocDefault));
+    stage.bytes = need * 2;
   }
-  char* hs = (char*)c->h_stage;
+  char* hs = (char*)stage.h;
   if (b_shapes) std::memcpy(hs, B.shapes.data(), b_shapes);
   std::memcpy(hs + b_shapes, B.objects.data(), b_obj);
   std::memcpy(hs + b_shapes + b_obj, B.samples.data(), b_smp);
@@ -859,11 +859,12 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     int rcb = prepare_backgrounds(c, sl, n_tasks, B.bgprep.data(), st);
     if (rcb != OFDG_OK) return rcb;
   }
-  HIP_OK(c, hipEventRecord(c->stage_free, st));
-  c->stage_pending = true;
+  HIP_OK(c, hipEventRecord(stage.free_ev, st));
+  stage.pending = true;
   if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
   HIP_OK(c, hipEventRecord(sl.ev_uploaded, st));
   sl.upload_pending = true;
+  sl.upload_stream = st;
   sl.res_samples = n_tasks;
   sl.res_shapes = (int)n_shapes;
   sl.res_objects = (int)n_obj;
@@ -876,9 +877,11 @@ int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blu
     if (c) c->err = "ofdg_render: invalid argument";
     return OFDG_EINVAL;
   }
-  int rc = upload_slot(c, c->slots[0], tasks, n_tasks, bps, n_bps, (hipStream_t)stream);
+  // the batch's records travel on the chain's own stream into its private slot
+  ofdg_ctx::Chain& ch = take_chain(c);
+  int rc = upload_slot(c, ch.slot, tasks, n_tasks, bps, n_bps, chain_stream(c, ch, (hipStream_t)stream), ch.stage);
   if (rc != OFDG_OK) return rc;
-  return launch_resident(c, c->slots[0], d_img0, d_img1, d_flow, (hipStream_t)stream);
+  return launch_resident(c, ch, ch.slot, d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
 
 int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps, int n_bps,
@@ -887,17 +890,22 @@ int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks,
     if (c) c->err = "ofdg_upload_slot: invalid argument";
     return OFDG_EINVAL;
   }
-  return upload_slot(c, c->slots[slot], tasks, n_tasks, bps, n_bps, (hipStream_t)stream);
+  return upload_slot(c, c->slots[slot], tasks, n_tasks, bps, n_bps, (hipStream_t)stream, c->user_stage);
 }
 
 int ofdg_render_slot(ofdg_ctx* c, int slot, float* d_img0, float* d_img1, float* d_flow, void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || slot < 0 || slot >= ofdg_ctx::kUserSlots) return OFDG_EINVAL;
   if (c->slots[slot].res_samples <= 0) { c->err = "ofdg_render_slot: no batch is resident in this slot"; return OFDG_EINVAL; }
-  return launch_resident(c, c->slots[slot], d_img0, d_img1, d_flow, (hipStream_t)stream);
+  return launch_resident(c, take_chain(c), c->slots[slot], d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
 
 int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
-  return ofdg_render_slot(c, 0, d_img0, d_img1, d_flow, stream);
+  if (!c || !d_img0 || !d_img1 || !d_flow) return OFDG_EINVAL;
+  if (!c->last_slot || c->last_slot->res_samples <= 0) { c->err = "ofdg_render_resident: nothing has been rendered yet"; return OFDG_EINVAL; }
+  // a chain's private slot is not tracked by events while only that chain uses it: let its owner drain first
+  for (int k = 0; k < c->n_chains; ++k)
+    if (&c->chains[k].slot == c->last_slot && !c->last_slot->compose_pending) HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
+  return launch_resident(c, take_chain(c), *c->last_slot, d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
 
 // size slot `sl` for n device-sampled samples: a fixed number of shape slots per sample
@@ -918,9 +926,9 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n));
   const size_t need_cov = shapes_cap * 2 * (size_t)W * H + 16;
-  if (need_cov > c->d_cov2[0].cap) {
+  if (need_cov > c->chains[0].cov.cap) {
     HIP_OK(c, hipDeviceSynchronize());
-    for (auto& ws : c->d_cov2) HIP_OK(c, ws.reserve(need_cov));
+    for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, c->chains[k].cov.reserve(need_cov));
   }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
@@ -945,30 +953,20 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
 int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
                          void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
-  // A ring of four private slots.  After launching batch i the sampler is started for the
-  // batch the caller will most likely ask for next (same stride as last time) on its own
-  // stream, so that it overlaps geom/raster of batch i and compose of batch i-1; a wrong
-  // guess only costs the unused launch.
-  ofdg_ctx::Slot& sl = c->slots[ofdg_ctx::kUserSlots + (int)(c->cs_calls & 3)];
-  ofdg_ctx::Slot& nx = c->slots[ofdg_ctx::kUserSlots + (int)((c->cs_calls + 1) & 3)];
-  c->cs_calls++;
-  int rc = prepare_counter_slot(c, sl, n_samples);
+  // the chain samples and realises the batch on the device, then renders it: all in order on its stream
+  ofdg_ctx::Chain& ch = take_chain(c);
+  int rc = prepare_counter_slot(c, ch.slot, n_samples);
   if (rc != OFDG_OK) return rc;
-  rc = launch_resident(c, sl, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
-  if (rc != OFDG_OK) return rc;
-  const long long delta = c->cs_last_index >= 0 && first_index > c->cs_last_index ? first_index - c->cs_last_index : n_samples;
-  c->cs_last_index = first_index;
-  if (c->overlap) {
-    rc = prepare_counter_slot(c, nx, n_samples);
-    if (rc != OFDG_OK) return rc;
-    if (nx.sampled_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_sampled, 0));
-    if (nx.compose_pending) HIP_OK(c, hipStreamWaitEvent(c->cs_stream, nx.ev_composed, 0));
-    if (!nx.ev_sampled) HIP_OK(c, hipEventCreateWithFlags(&nx.ev_sampled, hipEventDisableTiming));
-    rc = launch_counter_sampler(c, nx, first_index + delta, c->cs_stream, nx.ev_sampled);
-    if (rc != OFDG_OK) return rc;
-    nx.sampled_pending = true;
-  }
-  return OFDG_OK;
+  return launch_resident(c, ch, ch.slot, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
+}
+
+// The internal stream the NEXT render / forward call of this context works on (the chains take turns).
+// A caller that passes it as that call's `stream` gets the outputs ordered on it and no cross-stream wait
+// at all; with any other stream the call waits for the work enqueued there before and the stream waits
+// for the outputs (standard stream semantics, but consecutive calls then serialise on that stream).
+void* ofdg_stream(ofdg_ctx* c) {
+  if (!c) return nullptr;
+  return (void*)c->chains[c->next_chain % (unsigned)c->n_chains].stream;
 }
 
 // Download the blueprints the counter sampler produces for samples first_index.. (tests):
@@ -1023,7 +1021,7 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
 int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   if (!c) return OFDG_EINVAL;
   HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
-  HIP_OK(c, hipStreamSynchronize(c->prep_stream));
+  for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
   uint32_t e = 0;
   HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
   if (e) {
@@ -1166,10 +1164,10 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   ofdg_ctx::Slot& sl = c->slots[0];
   HIP_OK(c, sl.d_frames.reserve(2));
   HIP_OK(c, sl.d_verts.reserve(2 * kMaxVerts));
-  HIP_OK(c, c->d_cov2[0].reserve((size_t)2 * W * H + 16));
+  HIP_OK(c, c->chains[0].cov.reserve((size_t)2 * W * H + 16));
   HIP_OK(c, hipMemcpy(sl.d_frames.p, &f, sizeof(f), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_verts.p, v.data(), sizeof(int2) * kMaxVerts, hipMemcpyHostToDevice));
-  HIP_OK(c, hipMemset(c->d_cov2[0].p, 0xAB, (size_t)W * H));  // poison: every byte must be written
+  HIP_OK(c, hipMemset(c->chains[0].cov.p, 0xAB, (size_t)W * H));  // poison: every byte must be written
   const int bands = (H + kBandRows - 1) / kBandRows;
   std::vector<int4> items;
   for (int b = 0; b < bands; ++b)
@@ -1180,42 +1178,46 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(raster_kernel, dim3(64 * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
-                     W, H, c->d_cov2[0].p, nullptr, 0, (unsigned long long*)nullptr);
+                     W, H, c->chains[0].cov.p, nullptr, 0, (unsigned long long*)nullptr);
   HIP_OK(c, hipGetLastError());
-  HIP_OK(c, hipMemcpy(coverage_host, c->d_cov2[0].p, (size_t)W * H, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(coverage_host, c->chains[0].cov.p, (size_t)W * H, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
-  for (auto& s2 : c->slots) s2.res_samples = 0;  // the workspaces no longer hold a rendered batch
+  sl.res_samples = 0;  // (slot 0 served as scratch)
+  c->last_slot = nullptr;
   return OFDG_OK;
 }
 int ofdg_debug_num_shapes(ofdg_ctx* c, int sample) {
-  if (!c || c->slots[0].res_samples <= 0 || sample < 0 || sample >= (int)c->slots[0].batch.samples.size()) return OFDG_EINVAL;
-  return c->slots[0].batch.samples[sample].n_shapes;
+  if (!c || !c->last_slot) return OFDG_EINVAL;
+  const ofdg_ctx::Slot& sl = *c->last_slot;
+  if (sl.res_samples <= 0 || sample < 0 || sample >= (int)sl.batch.samples.size()) return OFDG_EINVAL;
+  return sl.batch.samples[sample].n_shapes;
 }
 
 int ofdg_debug_coverage(ofdg_ctx* c, int sample, int shape, int frame, uint8_t* coverage_host) {
-  if (!c || !coverage_host || frame < 0 || frame > 1 || c->slots[0].res_samples <= 0) return OFDG_EINVAL;
-  if (sample < 0 || sample >= (int)c->slots[0].batch.samples.size()) return OFDG_EINVAL;
-  const DevSample& s = c->slots[0].batch.samples[sample];
+  if (!c || !coverage_host || frame < 0 || frame > 1 || !c->last_slot || c->last_slot->res_samples <= 0) return OFDG_EINVAL;
+  const ofdg_ctx::Slot& sl = *c->last_slot;
+  if (sample < 0 || sample >= (int)sl.batch.samples.size()) return OFDG_EINVAL;
+  const DevSample& s = sl.batch.samples[sample];
   if (shape < 0 || shape >= s.n_shapes) return OFDG_EINVAL;
   const int W = c->prm.width, H = c->prm.height;
   const size_t sf = (size_t)(s.first_shape + shape) * 2 + frame;
   HIP_OK(c, hipDeviceSynchronize());
   DevShapeFrame f;
-  HIP_OK(c, hipMemcpy(&f, c->slots[0].d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(&f, sl.d_frames.p + sf, sizeof(f), hipMemcpyDeviceToHost));
   std::vector<uint8_t> tmp((size_t)W * H);
-  HIP_OK(c, hipMemcpy(tmp.data(), c->d_cov2[c->last_parity].p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(tmp.data(), c->chains[c->last_chain].cov.p + sf * W * H, tmp.size(), hipMemcpyDeviceToHost));
   std::memset(coverage_host, 0, tmp.size());
   for (int y = f.y0; y <= f.y1; ++y)
     for (int x = f.x0; x <= f.x1; ++x) coverage_host[(size_t)y * W + x] = tmp[(size_t)y * W + x];
   return OFDG_OK;
 }
 
-// number of raster work items of the last launch of slot 0 (diagnostics)
+// number of raster work items left by the last launch (diagnostics)
 int ofdg_debug_item_count(ofdg_ctx* c) {
-  if (!c || !c->slots[0].d_item_count) return OFDG_EINVAL;
+  if (!c || !c->last_slot || !c->last_slot->d_item_count) return OFDG_EINVAL;
   int n = 0;
   if (hipDeviceSynchronize() != hipSuccess) return OFDG_EHIP;
-  if (hipMemcpy(&n, c->slots[0].d_item_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return OFDG_EHIP;
+  if (hipMemcpy(&n, c->last_slot->d_item_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return OFDG_EHIP;
   return n;
 }
 

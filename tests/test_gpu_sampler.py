@@ -235,10 +235,13 @@ def test_counter_sampler_has_room_for_the_worst_case_sample(ofdg):
     assert torch.isfinite(fl).all()
 
 
-def test_interleaved_entry_points_give_the_same_bytes_as_isolated_calls(ofdg):
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_interleaved_entry_points_give_the_same_bytes_as_isolated_calls(ofdg, own_stream):
     """Stream/event plumbing: ofdg_render, ofdg_render_slot on several resident slots and ofdg_forward_counter
-    interleaved at random on one context (three streams, rotating coverage workspaces, sample-ahead) produce
-    exactly what each call produces on a fresh context."""
+    interleaved at random on one context (in-order chains taking turns, one coverage workspace and one private
+    slot each, user slots shared between them) produce exactly what each call produces on a fresh context -
+    both when the caller passes its own stream (cross-stream hand-over) and when it passes ofdg_stream(),
+    where consecutive calls overlap on the device."""
     import torch
     W, H, B = 128, 96, 3
     rng = np.random.default_rng(0)
@@ -270,22 +273,25 @@ def test_interleaved_entry_points_give_the_same_bytes_as_isolated_calls(ofdg):
         g.upload_slot(k, t, B, b, n)
     outs = [ofdg.alloc_outputs(B, H, W) for _ in range(3)]
     log = []
+    seen = set()
     for step in range(40):
         o = outs[step % 3]
         r = rng.integers(0, 3)
+        st = g.next_stream() if own_stream else 0
+        seen.add(st)
         if r == 0:
             i = int(rng.choice([0, 3, 6, 9, 50]))
-            g.forward_counter(i, B, *o)
+            g.forward_counter(i, B, *o, st)
             key = ("counter", i)
         elif r == 1:
             k = int(rng.integers(0, 4))
-            g.render_slot(k, *o)
+            g.render_slot(k, *o, st)
             key = ("host", k)
         else:
             k = int(rng.integers(0, 4))
             t, b, n = batches[k]
-            g.render(t, B, b, n, *o)   # (re-uploads into slot 0)
-            g.upload_slot(0, *batches[0][:1], B, batches[0][1], batches[0][2])
+            g.render(t, B, b, n, *o, st)   # (records travel into the chain's private slot)
+            g.upload_slot(0, *batches[0][:1], B, batches[0][1], batches[0][2])   # (slot 0 replaced while in use)
             key = ("host", k)
         log.append((step % 3, key))
         if step % 3 == 2 or step == 39:   # check the buffers written since the last check
@@ -294,3 +300,26 @@ def test_interleaved_entry_points_give_the_same_bytes_as_isolated_calls(ofdg):
                 for a, w in zip(outs[bi], want[kk]):
                     assert torch.equal(a, w), (step, kk)
             log = []
+    assert len(seen) == (3 if own_stream else 1) and (0 not in seen or not own_stream)   # the chains take turns
+
+
+def test_render_resident_repeats_the_last_call(ofdg):
+    """ofdg_render_resident re-renders the records of the last render / forward call (whichever chain they live
+    on) into other buffers: identical bytes."""
+    import torch
+    W, H, B = 128, 96, 2
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=3, batch_size=B))
+    g.pool_synthetic(3, 256, 192, 2)
+    a = ofdg.alloc_outputs(B, H, W)
+    b = ofdg.alloc_outputs(B, H, W)
+    t, bp, n = ofdg.HostSampler(7, W, H).next(B, cap=B * 64)
+    for first in (lambda: g.render(t, B, bp, n, *a, g.next_stream()), lambda: g.forward_counter(11, B, *a)):
+        first()
+        for _ in range(4):   # (every repeat runs on the next chain)
+            for x in b:
+                x.zero_()
+            torch.cuda.synchronize()
+            g.render_resident(*b, g.next_stream())
+            g.synchronize()
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)

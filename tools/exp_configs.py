@@ -13,11 +13,11 @@ def run(name, W, H, mode, B, nobj, pool, steps=200):
     g.pool_synthetic(*pool, 1)
     if mode == 9:
         g.warp_generate(2, 1)
-    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(2)]
+    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(4)]
     st = torch.cuda.current_stream().cuda_stream
-    for i in range(20): g.forward_counter(i * B, B, *outs[i % 2], st)
+    for i in range(20): g.forward_counter(i * B, B, *outs[i % 4], g.next_stream())
     torch.cuda.synchronize(); t = time.perf_counter()
-    for i in range(steps): g.forward_counter((20 + i) * B, B, *outs[i % 2], st)
+    for i in range(steps): g.forward_counter((20 + i) * B, B, *outs[i % 4], g.next_stream())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / steps
     g.synchronize(st)
     px = W * H * B / dt

@@ -26,18 +26,18 @@ for slot in range(NS):
             for i in range(n):
                 if i != t.background: bps[i].do_warpfield_deformation = 0
     g.upload_slot(slot, tasks, B, bps, n, st)
-i0, i1, fl = ofdg.alloc_outputs(B, H, W)
-for i in range(20): g.render_slot(i % NS, i0, i1, fl, st)
+outs = [ofdg.alloc_outputs(B, H, W) for _ in range(4)]
+for i in range(20): g.render_slot(i % NS, *outs[i % 4], g.next_stream())
 g.synchronize(st)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(200): g.render_slot(i % NS, i0, i1, fl, st)
+for i in range(200): g.render_slot(i % NS, *outs[i % 4], g.next_stream())
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
 g.set_profiling(2)
-for i in range(64): g.render_slot(i % NS, i0, i1, fl, st)
+for i in range(64): g.render_slot(i % NS, *outs[i % 4], g.next_stream())
 g.synchronize(st)
 print("bgonly=%s mode=%d step=%.1f us  geom=%.1f raster=%.1f compose=%.1f us  -> %.0f samples/s" % (
     bool(os.environ.get("BGONLY")), MODE, dt * 1e6,
     g.kernel_ms("geom") * 1e3, g.kernel_ms("raster") * 1e3, g.kernel_ms("compose") * 1e3, B / dt))
 import ctypes
-g.render_slot(0, i0, i1, fl, st); g.synchronize(st)
+g.render_slot(0, *outs[0], st); g.synchronize(st)
 print("raster items in slot 0:", ofdg.lib().ofdg_debug_item_count(g.h))

@@ -697,15 +697,18 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   sl.mask_used[bp] = sl.res_samples * dm.tiles_x * ((H + kBandRows - 1) / kBandRows) * 2;
   const int n_mask_words = sl.mask_used[bp ^ 1];
   const bool prof_prep = ev && c->profiling == 2;
-  // (profiled launches: start/stop events ride on the kernels' own dispatch packets)
+  // Profiled launches: a kernel's time is the span between the completion of its predecessor on the
+  // chain's stream and its own completion - both taken from the kernels' own dispatch packets (stop
+  // events).  A start event would be a marker packet in front of the kernel, which delays its dispatch
+  // by ~10 us and is then counted as kernel time; only geom (first of the three) has one.
   hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, S,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
                         sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
-    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, prof_prep ? ev[2] : nullptr,
-                          prof_prep ? ev[3] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
+    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
+                          ev ? ev[3] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
                           box_next, n_mask_words, box_cur);
     HIP_OK(c, hipGetLastError());
   }
@@ -723,7 +726,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
     if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
     done = sl.ev_composed;
   }
-  hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
+  hipEvent_t k_start = nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
@@ -1238,7 +1241,7 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
 
 // Average device time (ms) per launch of one kernel over the launches recorded since
 // ofdg_set_profiling (at most the last 256), from HIP events attached to the kernels' dispatch
-// packets on their launch streams (start and end of the kernel itself).
+// packets on their launch streams: completion of the predecessor .. completion of the kernel.
 int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   if (!c || !kernel || !ms) return OFDG_EINVAL;
   int i = -1;
@@ -1256,7 +1259,8 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
     hipEvent_t* ev = &c->ev[(size_t)k * 6];
     HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
-    HIP_OK(c, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    // geom: its own start marker .. its end; raster: end of geom .. its end; compose: end of raster .. its end
+    HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : 2 * i - 1], ev[2 * i + 1]));
     acc += t;
   }
   *ms = (float)(acc / n);

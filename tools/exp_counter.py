@@ -15,10 +15,11 @@ st = (lambda: st0) if OWN else g.next_stream
 for i in range(20): g.forward_counter(i * B, B, *outs[i % NBUF], st())
 torch.cuda.synchronize()
 N = int(os.environ.get("N", "300"))
-g.set_profiling(1)
+PROF = not os.environ.get("NOPROF")
+if PROF: g.set_profiling(1)
 t = time.perf_counter()
 for i in range(N): g.forward_counter((20 + i) * B, B, *outs[i % NBUF], st())
 t_host = (time.perf_counter() - t) / N
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / N
-print(f"counter-sampler forward mode={MODE} nbuf={NBUF}: step={dt*1e6:.1f} us (compose kernel {g.kernel_ms('compose')*1e3:.1f} us, host enqueue {t_host*1e6:.1f} us/step) -> {B/dt:.0f} samples/s")
+print(f"counter-sampler forward mode={MODE} nbuf={NBUF}: step={dt*1e6:.1f} us (compose kernel {(g.kernel_ms('compose') if PROF else 0)*1e3:.1f} us, host enqueue {t_host*1e6:.1f} us/step) -> {B/dt:.0f} samples/s")

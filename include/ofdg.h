@@ -164,14 +164,15 @@ int ofdg_sample(ofdg_ctx* ctx, int n_tasks, ofdg_task* tasks,
  * load_batch (LAY:227-250).  Renders task i into slot i of the caller-owned
  * DEVICE buffers image0 [n,3,H,W], image1 [n,3,H,W], flow [n,2,H,W] (float32,
  * planar, B,G,R order, 0..255).  Asynchronous on `stream` (a hipStream_t): the
- * call starts writing the outputs after the work enqueued on `stream` before it,
- * and work enqueued on `stream` after it sees them.  Internally the context owns a
- * few in-order streams ("chains", taking turns call by call) on which the record
- * upload / device sampler, the outline, coverage and compose kernels of one call
- * run back to back while those of the neighbouring calls overlap them; pass
- * ofdg_stream(ctx) as `stream` to be ordered on that internal stream directly
- * (no cross-stream wait; consecutive calls then overlap - the fast way to drive
- * a prefetch ring: one output buffer set per call in flight).
+ * outputs are written by a kernel on `stream`, after the work enqueued there before
+ * the call, and work enqueued there after it sees them.  Internally the context owns
+ * a few in-order streams ("chains", taking turns call by call) on which the record
+ * upload / device sampler and the outline and coverage kernels of one call run back
+ * to back, overlapping the neighbouring calls; the compose kernel follows on
+ * `stream` after one event.  Pass ofdg_stream(ctx) as `stream` to run compose on the
+ * chain's own stream too (no cross-stream wait at all; the compose kernels of
+ * consecutive calls then overlap as well - the fast way to drive a prefetch ring:
+ * one output buffer set per call in flight).
  */
 int ofdg_render(ofdg_ctx* ctx, const ofdg_task* tasks, int n_tasks,
                 const ofdg_blueprint* bps, int n_bps,

@@ -81,7 +81,7 @@ struct ofdg_ctx {
     DevBuf<DevCropRef> d_croptab;      // mode 9: crops of this batch's deforming objects
     DevBuf<float> d_bgwarp;            // mode 9: upscaled (2W x 2H) background crops
     DevBuf<unsigned> d_bgwarp_max;
-    hipEvent_t ev_composed = nullptr;  // last compose that read this slot's records ...
+    hipEvent_t compose_event = nullptr;  // last tracked compose that read this slot's records (alias of a chain's ev_done) ...
     bool compose_pending = false;
     hipStream_t compose_stream = nullptr;  // ... and the stream it ran on
     int* d_item_count = nullptr;
@@ -109,7 +109,10 @@ struct ofdg_ctx {
     DevBuf<uint8_t> cov;
     Slot slot;
     Stage stage;
-    hipEvent_t ev_in = nullptr;   // the caller's stream at call time (outputs may still be read there)
+    hipEvent_t ev_prep = nullptr;  // coverage ready (hand-over to a caller's stream)
+    hipEvent_t ev_done = nullptr;  // the chain's last tracked compose ...
+    bool done_pending = false;
+    hipStream_t done_stream = nullptr;  // ... and the stream it ran on (the chain's own, or a caller's)
   };
   static constexpr int kMaxChains = 8;
   Chain chains[kMaxChains];
@@ -252,7 +255,8 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     ofdg_ctx::Chain& ch = c->chains[i];
     if ((e = hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ch.stage.free_ev, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ch.ev_in, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&ch.ev_prep, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ch.ev_done, hipEventDisableTiming)) != hipSuccess) {
       g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
       return OFDG_EHIP;
     }
@@ -284,7 +288,6 @@ void ofdg_destroy(ofdg_ctx* c) {
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
-    if (sl.ev_composed) (void)hipEventDestroy(sl.ev_composed);
   };
   auto drop_stage = [](ofdg_ctx::Stage& g) {
     if (g.h) (void)hipHostFree(g.h);
@@ -296,7 +299,8 @@ void ofdg_destroy(ofdg_ctx* c) {
     drop_slot(ch.slot);
     drop_stage(ch.stage);
     ch.cov.release();
-    if (ch.ev_in) (void)hipEventDestroy(ch.ev_in);
+    if (ch.ev_prep) (void)hipEventDestroy(ch.ev_prep);
+    if (ch.ev_done) (void)hipEventDestroy(ch.ev_done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
   }
   if (c->d_rs_xi) { (void)hipFree(c->d_rs_xi); (void)hipFree(c->d_rs_xa); (void)hipFree(c->d_rs_yi); (void)hipFree(c->d_rs_ya); }
@@ -644,8 +648,8 @@ static ofdg_ctx::Chain& take_chain(ofdg_ctx* c) {
 static hipStream_t chain_stream(const ofdg_ctx* c, const ofdg_ctx::Chain& ch, hipStream_t st) { return c->overlap ? ch.stream : st; }
 
 // [counter sampler ->] geom -> raster -> compose of the batch resident in `sl`, in order on chain `ch`.
-// `st` is the caller's stream: if it is not the chain's own stream (ofdg_stream), compose additionally waits
-// for what the caller enqueued before the call (the outputs may still be read there) and `st` waits for compose.
+// `st` is the caller's stream: if it is not the chain's own stream (ofdg_stream), compose runs on `st` instead,
+// behind what the caller enqueued there (the outputs may still be read) and behind the chain's raster kernel.
 static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow,
                            hipStream_t st, long long cs_first_index = -1) {
   const int W = c->prm.width, H = c->prm.height;
@@ -679,9 +683,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
     if (hipEventQuery(sl.ev_uploaded) == hipSuccess) sl.upload_pending = false;
     else HIP_OK(c, hipStreamWaitEvent(S, sl.ev_uploaded, 0));
   }
+  // the chain's workspace (and private slot) may still be read by its previous compose if that ran on a caller's stream
+  if (ch.done_pending && ch.done_stream != S) {
+    if (hipEventQuery(ch.ev_done) != hipSuccess) HIP_OK(c, hipStreamWaitEvent(S, ch.ev_done, 0));
+    ch.done_pending = false;  // (the chain's stream is ordered behind it from here on)
+  }
   if (sl.compose_pending && sl.compose_stream != S) {
-    if (hipEventQuery(sl.ev_composed) == hipSuccess) sl.compose_pending = false;
-    else HIP_OK(c, hipStreamWaitEvent(S, sl.ev_composed, 0));
+    if (hipEventQuery(sl.compose_event) == hipSuccess) sl.compose_pending = false;
+    else HIP_OK(c, hipStreamWaitEvent(S, sl.compose_event, 0));
   }
   // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
   const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
@@ -707,50 +716,56 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   HIP_OK(c, hipGetLastError());
   {
     static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
+    // (a caller's stream takes the coverage over with the event on raster's own packet)
     hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
-                          ev ? ev[3] : nullptr, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
+                          ev ? ev[3] : (foreign ? ch.ev_prep : nullptr), 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
                           box_next, n_mask_words, box_cur);
     HIP_OK(c, hipGetLastError());
   }
   const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
   const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
+  // Where compose runs: on the chain's stream, right behind raster - or, if the caller passed another stream,
+  // on THAT stream (in order with the caller's own work, which may still read the outputs) once the coverage
+  // is ready.  It is tracked by the chain's event whenever somebody else may have to wait for it: the chain
+  // itself (workspace, private slot) after a compose on a caller's stream, other chains for a shared slot.
+  hipStream_t CS = S;
   if (foreign) {
-    HIP_OK(c, hipEventRecord(ch.ev_in, st));
-    HIP_OK(c, hipStreamWaitEvent(S, ch.ev_in, 0));
+    if (ev) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
+    HIP_OK(c, hipStreamWaitEvent(st, ch.ev_prep, 0));
+    CS = st;
   }
-  // completion event of compose: for the caller's stream, and for whoever touches this slot from another stream
   const bool shared_slot = &sl != &ch.slot;
-  hipEvent_t done = nullptr;
-  if (foreign || shared_slot) {
-    if (!sl.ev_composed) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_composed, hipEventDisableTiming));
-    done = sl.ev_composed;
-  }
+  hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
   hipEvent_t k_start = nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if (c->prm.mode == 9)
-    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
     // makes room for the single-wave workgroups of the latency-bound preparation kernels of
     // the other chains, which therefore co-run with it.
-    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, S, k_start, k_stop, 0, dm, sl.d_samples.p,
+    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
-    if (done) HIP_OK(c, hipEventRecord(done, S));
+    if (done) HIP_OK(c, hipEventRecord(done, CS));
     c->ev_count++;
   }
-  if (done) { sl.compose_pending = true; sl.compose_stream = S; }
-  if (foreign) HIP_OK(c, hipStreamWaitEvent(st, done, 0));
+  if (done) {
+    sl.compose_pending = true; sl.compose_stream = CS; sl.compose_event = done;
+    ch.done_pending = true; ch.done_stream = CS;
+  } else {
+    sl.compose_pending = false;  // private slot on its own chain: stream order is all it needs
+  }
   return OFDG_OK;
 }
 
@@ -781,7 +796,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   if (stage.pending) { HIP_OK(c, hipEventSynchronize(stage.free_ev)); stage.pending = false; }
   // a compose on another stream may still read the records this upload replaces
   if (sl.compose_pending && sl.compose_stream != st) {
-    HIP_OK(c, hipStreamWaitEvent(st, sl.ev_composed, 0));
+    HIP_OK(c, hipStreamWaitEvent(st, sl.compose_event, 0));
     sl.compose_pending = false;
   }
   sl.res_samples = 0;
@@ -965,8 +980,8 @@ int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, floa
 
 // The internal stream the NEXT render / forward call of this context works on (the chains take turns).
 // A caller that passes it as that call's `stream` gets the outputs ordered on it and no cross-stream wait
-// at all; with any other stream the call waits for the work enqueued there before and the stream waits
-// for the outputs (standard stream semantics, but consecutive calls then serialise on that stream).
+// at all; with any other stream the compose kernel runs on that stream after one event (standard stream
+// semantics: the compose kernels of consecutive calls then run one after the other).
 void* ofdg_stream(ofdg_ctx* c) {
   if (!c) return nullptr;
   return (void*)c->chains[c->next_chain % (unsigned)c->n_chains].stream;
@@ -1024,7 +1039,10 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
 int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   if (!c) return OFDG_EINVAL;
   HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
-  for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
+  for (int k = 0; k < c->n_chains; ++k) {
+    HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
+    if (c->chains[k].done_pending) HIP_OK(c, hipEventSynchronize(c->chains[k].ev_done));  // (a compose on another caller stream)
+  }
   uint32_t e = 0;
   HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
   if (e) {

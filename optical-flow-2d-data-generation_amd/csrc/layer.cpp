@@ -19,7 +19,13 @@ namespace ofdg {
 // Blob
 // ---------------------------------------------------------------------------
 Blob::~Blob() {
-  if (data_) (void)hipFree(data_);
+  if (data_ && !external_) (void)hipFree(data_);
+}
+void Blob::set_gpu_data(float* data) {
+  if (data_ && !external_) (void)hipFree(data_);
+  data_ = data;
+  external_ = true;
+  capacity_ = 0;
 }
 void Blob::Reshape(const std::vector<int>& shape) {
   size_t n = 1;
@@ -29,6 +35,7 @@ void Blob::Reshape(const std::vector<int>& shape) {
   }
   shape_ = shape;
   count_ = n;
+  if (external_) return;  // (the owner of the memory sized it)
   if (n > capacity_) {
     if (data_) (void)hipFree(data_);
     data_ = nullptr;
@@ -262,12 +269,36 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt) : cf
   }
 }
 
-DataGenerationLayer::~DataGenerationLayer() { ofdg_destroy(ctx_); }
+DataGenerationLayer::~DataGenerationLayer() {
+  if (ctx_) (void)ofdg_synchronize(ctx_, nullptr);
+  for (float* p : ring_) if (p) (void)hipFree(p);
+  ofdg_destroy(ctx_);
+}
+
+// render the next batch of the stream into its buffer set, on the context's next internal stream
+void DataGenerationLayer::enqueue_next() {
+  const int P = (int)ring_.size() / 3;
+  float** set = &ring_[(size_t)(produced_ % P) * 3];
+  if (ofdg_forward(ctx_, set[0], set[1], set[2], ofdg_stream(ctx_)) != OFDG_OK)
+    throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+  ++produced_;
+}
 
 void DataGenerationLayer::LayerSetUp(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top) {
   if (!bottom.empty()) throw std::runtime_error("DataGeneration takes no bottom blobs");  // ExactNumBottomBlobs() == 0
   if (top.size() != 3) throw std::runtime_error("DataGeneration produces exactly 3 top blobs");  // load_batch indexes output[0..2]
   const int N = cfg_.params.batch_size, H = cfg_.params.height, W = cfg_.params.width;
+  // StartInternalThread (data_generation_layer.cpp:132): the first prefetch - 1 batches start rendering now
+  const int P = cfg_.params.prefetch;
+  if (P > 1 && ring_.empty()) {
+    ring_.assign((size_t)P * 3, nullptr);
+    for (int k = 0; k < P * 3; ++k)
+      if (hipMalloc((void**)&ring_[k], (size_t)N * (k % 3 == 2 ? 2 : 3) * H * W * sizeof(float)) != hipSuccess)
+        throw std::runtime_error("DataGenerationLayer: hipMalloc of the prefetch buffers failed");
+    while (produced_ < P - 1) enqueue_next();
+  }
+  if (!ring_.empty())
+    for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(ring_[k]);  // (the tops never own memory in this mode)
   top[0]->Reshape({N, 3, H, W});  // data_generation_layer.cpp:128-130
   top[1]->Reshape({N, 3, H, W});
   top[2]->Reshape({N, 2, H, W});
@@ -280,6 +311,18 @@ void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const st
   top[0]->Reshape({N, 3, H, W});
   top[1]->Reshape({N, 3, H, W});
   top[2]->Reshape({N, 2, H, W});
+  if (!ring_.empty()) {
+    // prefetch_full_.pop (data_generation_layer.cpp:269): the oldest batch in flight - finished long ago when the
+    // caller's own work takes longer than a render - becomes the tops; its successor starts rendering at once
+    const int P = (int)ring_.size() / 3;
+    if (produced_ == consumed_) enqueue_next();
+    if (ofdg_synchronize(ctx_, nullptr) != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+    float** set = &ring_[(size_t)(consumed_ % P) * 3];
+    for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
+    ++consumed_;
+    while (produced_ < consumed_ + P - 1) enqueue_next();
+    return;
+  }
   int rc = ofdg_forward(ctx_, top[0]->mutable_gpu_data(), top[1]->mutable_gpu_data(), top[2]->mutable_gpu_data(), nullptr);
   if (rc == OFDG_OK) rc = ofdg_synchronize(ctx_, nullptr);
   if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));

@@ -21,7 +21,9 @@ class Blob {
   ~Blob();
   Blob(const Blob&) = delete;
   Blob& operator=(const Blob&) = delete;
-  void Reshape(const std::vector<int>& shape);  // (re)allocates device memory
+  void Reshape(const std::vector<int>& shape);  // (re)allocates device memory (unless the data is external)
+  // caffe::Blob::set_gpu_data: point the blob at external device memory (not owned; the shape stays)
+  void set_gpu_data(float* data);
   const std::vector<int>& shape() const { return shape_; }
   size_t count() const { return count_; }
   size_t offset(int n, int c = 0, int h = 0, int w = 0) const;
@@ -32,6 +34,7 @@ class Blob {
   std::vector<int> shape_;
   size_t count_ = 0, capacity_ = 0;
   float* data_ = nullptr;
+  bool external_ = false;
 };
 
 // What the prototxt subset parser extracts (src/caffe/proto/caffe.proto:6-12 and
@@ -60,7 +63,12 @@ class DataGenerationLayer {
   inline int MinTopBlobs() const { return 1; }
 
   // The reference's Forward_gpu defers to Forward_cpu (data_generation_layer.cpp:286-291);
-  // here both produce the batch on the GPU, directly into the top blobs.
+  // here both produce the batch on the GPU.  data_param.prefetch = 1: rendered into the top
+  // blobs' own memory.  prefetch = P > 1 (the reference's prefetch thread and its queue of P
+  // batches, data_generation_layer.cpp:36-56, 141-172, 266-282): P device buffer sets are
+  // cycled, P - 1 batches are rendered ahead on the context's internal streams (from
+  // LayerSetUp on) while the caller works on the current one, and Forward points the top
+  // blobs at the finished set instead of copying it (valid until the next Forward).
   void Forward_cpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Forward_gpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Backward_cpu(const std::vector<Blob*>&, const std::vector<bool>&, const std::vector<Blob*>&) {}
@@ -70,8 +78,11 @@ class DataGenerationLayer {
   ofdg_ctx* context() { return ctx_; }
 
  private:
+  void enqueue_next();
   LayerConfig cfg_;
   ofdg_ctx* ctx_ = nullptr;
+  std::vector<float*> ring_;       // [prefetch][3] device buffers (prefetch > 1)
+  long long produced_ = 0, consumed_ = 0;
 };
 
 // Texture list loader: TextureCollection (DataGenerator.cpp:117-149) for binary PPM

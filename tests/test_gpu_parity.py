@@ -344,6 +344,26 @@ def test_layer_surface_forward_matches_oracle(ofdg, oracle, tmp_path):
     assert e.value.code == ofdg.EBADMODE
 
 
+def test_layer_prefetch_ring_yields_the_same_batches(ofdg):
+    """data_param.prefetch = P > 1: the layer renders P - 1 batches ahead into a ring of buffer sets on the
+    context's internal streams and Forward hands out the finished set - the same batches, in the same order,
+    as the unprefetched layer (both samplers)."""
+    import torch
+    for sampler in (0, 1):
+        proto = """layer { name: "d" type: "DataGeneration" top: "a" top: "b" top: "f"
+          data_param { batch_size: 2 prefetch: %d }
+          data_generation_param { mode: 5 texture_dbases: "synthetic:3:256:192:4" width: 128 height: 96 sampler: %d seed: 3 } }"""
+        seqs = []
+        for prefetch in (1, 2, 4):
+            layer = ofdg.DataGenerationLayer(proto % (prefetch, sampler))
+            seqs.append([layer.Forward() for _ in range(6)])
+            layer.close()
+        for other in seqs[1:]:
+            for x, y in zip(seqs[0], other):
+                assert all(torch.equal(a, b) for a, b in zip(x, y))
+        assert not torch.equal(seqs[0][0][0], seqs[0][1][0])   # (consecutive batches differ)
+
+
 def test_forward_shards_across_ranks(ofdg, oracle):
     """ofdg_forward with rank/world_size: rank r renders block r of every B*world tasks."""
     W, H, B = 128, 96, 2

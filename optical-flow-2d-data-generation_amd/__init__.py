@@ -207,6 +207,37 @@ class Generator:
         _, h, w = a.shape
         self._check(lib().ofdg_pool_upload_mixed(self.h, index, a.ctypes.data_as(C.c_void_p), w, h))
 
+    def pool_from_list(self, list_path):
+        """TextureCollection (DataGenerator.cpp:117-149) for any image format Pillow decodes: `list_path` is the
+        reference's texture_dbases file, one image path per line (a last line without a trailing newline is
+        dropped, DG:124-126).  Images are decoded on the host to 8-bit RGB, stored as planar B, G, R (the
+        reference swaps R and B after CImg::load, DG:128-131) and uploaded; images of one size are kept whole,
+        a list with different sizes becomes a mixed pool.  Returns the number of images."""
+        import numpy as np
+        from PIL import Image
+        with open(list_path, "r") as f:
+            text = f.read()
+        paths = [ln for ln in text.split("\n")[:-1] if ln.strip()]
+        if not paths:
+            raise OfdgError(ETEXTURES, "Could not open texture collection (%s lists no image)" % list_path)
+        imgs = []
+        for pth in paths:
+            try:
+                rgb = np.asarray(Image.open(pth).convert("RGB"), np.uint8)
+            except Exception as e:
+                raise OfdgError(ETEXTURES, "Could not open texture collection (cannot read %s: %s)" % (pth, e))
+            imgs.append(np.ascontiguousarray(rgb[:, :, ::-1].transpose(2, 0, 1)))
+        if len({im.shape for im in imgs}) == 1:
+            _, h, w = imgs[0].shape
+            self.pool_alloc(len(imgs), w, h)
+            for i, im in enumerate(imgs):
+                self.pool_upload(i, im)
+        else:
+            self.pool_alloc_mixed(len(imgs))
+            for i, im in enumerate(imgs):
+                self.pool_upload_mixed(i, im)
+        return len(imgs)
+
     def pool_download(self, index):
         import numpy as np
         n, w, h = C.c_int(), C.c_int(), C.c_int()

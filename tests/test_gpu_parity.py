@@ -590,3 +590,45 @@ def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_pat
     g.synchronize()
     assert torch.equal(a, i0) and torch.equal(b, i1) and torch.equal(f, fl)
     layer.close()
+
+
+def test_pool_from_list_decodes_images_like_the_ppm_loader(ofdg, tmp_path):
+    """Generator.pool_from_list (Pillow decode of any image format; the reference uses CImg::load) and
+    tools/convert_textures.py + the layer's PPM loader fill the pool with the same texels, in B, G, R order;
+    a last list line without a newline is dropped like in the reference (DG:124-126)."""
+    import subprocess, sys, os
+    import torch
+    from PIL import Image
+    rng = np.random.RandomState(2)
+    paths, planar = [], []
+    for i, fmt in enumerate(("png", "bmp", "png")):
+        rgb = rng.randint(0, 256, (192, 256, 3)).astype(np.uint8)
+        p = tmp_path / ("img%d.%s" % (i, fmt))
+        Image.fromarray(rgb).save(p)
+        paths.append(str(p))
+        planar.append(np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))
+    lst = tmp_path / "images.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3))
+    assert g.pool_from_list(str(lst)) == 3
+    assert np.array_equal(g.pool_download_all(), np.stack(planar))
+    lst2 = tmp_path / "images2.txt"
+    lst2.write_text("\n".join(paths))                     # no trailing newline: the last image is not loaded
+    g2 = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7))
+    assert g2.pool_from_list(str(lst2)) == 2
+    bad = tmp_path / "bad.txt"
+    bad.write_text(str(tmp_path / "not_an_image.png") + "\n")
+    with pytest.raises(ofdg.OfdgError) as e:
+        g2.pool_from_list(str(bad))
+    assert e.value.code == ofdg.ETEXTURES and "Could not open texture collection" in str(e.value)
+    # the converter writes PPMs + a list the C++ layer reads: same batches as the directly decoded pool
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "ppm"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "convert_textures.py"), str(lst), str(out)], check=True)
+    layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % (out / "database.txt"))
+    a, b, f = layer.Forward()
+    i0, i1, fl = ofdg.alloc_outputs(3, 96, 128)
+    g.forward(i0, i1, fl)
+    g.synchronize()
+    assert torch.equal(a, i0) and torch.equal(b, i1) and torch.equal(f, fl)
+    layer.close()

@@ -7,6 +7,7 @@ W, H, B = 512, 384, 32
 MODE = int(os.environ.get("MODE", "5")); NOBJ = int(os.environ.get("NOBJ", "16"))
 g = ofdg.Generator(ofdg.default_params(mode=MODE, batch_size=B, width=W, height=H, num_objects=NOBJ, sampler=1, seed=5, background_prep=int(os.environ.get("BGPREP", "0"))))
 g.pool_synthetic(1000, 1024, 768, seed=1)
+if MODE == 9: g.warp_generate(2, 1)
 NBUF = int(os.environ.get("NBUF", "4"))  # output buffer sets the caller cycles (prefetch ring)
 outs = [ofdg.alloc_outputs(B, H, W) for _ in range(NBUF)]
 OWN = os.environ.get("OWNSTREAM")  # 1: pass torch's stream (cross-stream hand-over) instead of the chain's own

@@ -17,6 +17,10 @@ A "step" is one pass of the whole hot path over one batch of 32 NEW samples:
       backgrounds together exceed the 256 MiB Infinity Cache); a step is geom -> raster ->
       compose.
 
+The calls are made the way a prefetch ring makes them: call k renders into output buffer set k mod 4 on the
+context's next internal stream (ofdg_stream), so the kernels of neighbouring steps overlap on the device; the
+timed region ends with a device-wide synchronisation.
+
 Samples shard across ranks with no data-path collective ("weak" scaling): rank r renders
 block r of every B*world consecutive samples of the stream.
 """

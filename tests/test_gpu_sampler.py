@@ -323,3 +323,33 @@ def test_render_resident_repeats_the_last_call(ofdg):
             g.synchronize()
             for x, y in zip(a, b):
                 assert torch.equal(x, y)
+
+
+def test_pipeline_shape_does_not_change_the_bytes(ofdg, tmp_path):
+    """OFDG_CHAINS (number of in-order chains) and OFDG_OVERLAP=0 (everything on the caller's stream) are
+    scheduling choices: the same calls produce the same bytes as the default three chains."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text('''
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+W, H, B = 128, 96, 3
+g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=6, batch_size=B))
+g.pool_synthetic(3, 256, 192, 2)
+outs = [ofdg.alloc_outputs(B, H, W) for _ in range(5)]
+for k in range(5):
+    g.forward_counter(7 * k, B, *outs[k], g.next_stream() if k %% 2 else 0)
+g.synchronize()
+np.savez(sys.argv[1], *[t.cpu().numpy() for o in outs for t in o])
+''' % root)
+    results = []
+    for env in ({}, {"OFDG_CHAINS": "1"}, {"OFDG_CHAINS": "2"}, {"OFDG_OVERLAP": "0"}):
+        out = tmp_path / ("out_%d.npz" % len(results))
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=e, timeout=300)
+        results.append(np.load(out))
+    for other in results[1:]:
+        for k in results[0].files:
+            assert np.array_equal(results[0][k], other[k]), k

@@ -148,6 +148,10 @@ int ofdg_pool_upload_mixed(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, 
 /* Download texture `index` as planar B,G,R u8 (w*h*3 bytes). */
 int ofdg_pool_download(ofdg_ctx* ctx, int index, uint8_t* bgr_planar);
 int ofdg_pool_info(const ofdg_ctx* ctx, int* n, int* w, int* h);
+/* The resident pool (one image size) as raw device memory, n*h*w BGRX texels: lets rank 0 load the texture
+ * collection (TextureCollection, DG:117-149) and the other ranks receive their replica with one RCCL broadcast
+ * over xGMI instead of reading the files again.  mark_written != 0: the caller is about to overwrite it. */
+int ofdg_pool_device(ofdg_ctx* ctx, void** ptr, unsigned long long* bytes, int mark_written);
 
 /*
  * Replaces the sampling half of load_batch (LAY:197-213):

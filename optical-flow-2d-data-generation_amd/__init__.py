@@ -69,7 +69,7 @@ _lib = None
 # every symbol include/ofdg.h declares
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
-    "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info",
+    "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
@@ -111,6 +111,7 @@ def lib():
         L.ofdg_pool_alloc.argtypes = [vp, i32, i32, i32]
         L.ofdg_pool_upload.argtypes = [vp, i32, vp, i32, i32]
         L.ofdg_pool_download.argtypes = [vp, i32, vp]
+        L.ofdg_pool_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_ulonglong), i32]
         L.ofdg_pool_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.ofdg_sample.argtypes = [vp, i32, vp, vp, i32, C.POINTER(i32)]
         L.ofdg_render.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
@@ -237,6 +238,26 @@ class Generator:
             for i, im in enumerate(imgs):
                 self.pool_upload_mixed(i, im)
         return len(imgs)
+
+    def pool_broadcast(self, src=0, group=None, chunk_bytes=1 << 30):
+        """Multi-GPU start-up: rank `src` has loaded the pool (pool_from_list / pool_upload / pool_synthetic), every
+        other rank has allocated one of the same shape (pool_alloc) - one torch.distributed broadcast (RCCL over
+        xGMI with the nccl backend) fills the replicas.  The reference has no counterpart (one process, one pool)."""
+        import torch
+        import torch.distributed as dist
+        ptr, nbytes = C.c_void_p(), C.c_ulonglong()
+        me = dist.get_rank(group)
+        self._check(lib().ofdg_pool_device(self.h, C.byref(ptr), C.byref(nbytes), 0 if me == src else 1))
+
+        class _Holder:
+            pass
+
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (int(nbytes.value),), "typestr": "|u1", "data": (int(ptr.value), False), "version": 2}
+        t = torch.as_tensor(h, device="cuda")
+        for off in range(0, t.numel(), chunk_bytes):
+            dist.broadcast(t[off:off + chunk_bytes], src=src, group=group)
+        torch.cuda.synchronize()
 
     def pool_download(self, index):
         import numpy as np

@@ -436,6 +436,19 @@ int ofdg_pool_info(const ofdg_ctx* c, int* n, int* w, int* h) {
   return OFDG_OK;
 }
 
+// The resident pool as raw device memory (n * h * w BGRX texels): for filling it from another GPU - rank 0 loads
+// the texture collection, the other ranks receive it with one RCCL broadcast over xGMI into their own replica.
+// `mark_written` != 0 tells the context that the contents changed (derived textures are rebuilt at the next use).
+int ofdg_pool_device(ofdg_ctx* c, void** ptr, unsigned long long* bytes, int mark_written) {
+  if (!c || !ptr || !bytes) return OFDG_EINVAL;
+  if (!c->pool || c->pool_mixed) { c->err = "pool_device: needs a pool of one image size (ofdg_pool_alloc / ofdg_pool_synthetic)"; return OFDG_ETEXTURES; }
+  HIP_OK(c, hipDeviceSynchronize());
+  *ptr = (void*)c->pool;
+  *bytes = (unsigned long long)c->pool_n * c->pool_w * c->pool_h * sizeof(uint32_t);
+  if (mark_written) c->pool_final = false;
+  return OFDG_OK;
+}
+
 // ---- sampler ---------------------------------------------------------------------------
 int ofdg_sample(ofdg_ctx* c, int n_tasks, ofdg_task* tasks, ofdg_blueprint* bps, int bps_capacity, int* n_bps) {
   if (!c || !tasks || !bps || !n_bps || n_tasks < 0) return OFDG_EINVAL;

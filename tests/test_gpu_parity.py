@@ -632,3 +632,49 @@ def test_pool_from_list_decodes_images_like_the_ppm_loader(ofdg, tmp_path):
     g.synchronize()
     assert torch.equal(a, i0) and torch.equal(b, i1) and torch.equal(f, fl)
     layer.close()
+
+
+def test_pool_broadcast_over_the_process_group(ofdg, tmp_path):
+    """Generator.pool_broadcast: the pool as raw device memory through torch.distributed (nccl = RCCL).  One GPU
+    here, so the group has one rank (the call path, the device view of the pool and the rebuild of derived
+    textures are what is checked); with more ranks the same call fills their replicas from rank 0."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "bcast.py"
+    script.write_text('''
+import importlib, os, sys, numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+W, H, B = 128, 96, 2
+g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=3, batch_size=B))
+g.pool_synthetic(3, 100, 80, 7)            # (smaller than 2W x 2H: the derived resized textures depend on the contents)
+before = g.pool_download_all()
+o1 = ofdg.alloc_outputs(B, H, W)
+g.forward_counter(0, B, *o1); g.synchronize()
+g.pool_broadcast(src=0)
+assert np.array_equal(g.pool_download_all(), before)
+# a receiver: allocate, then overwrite the device view (what the broadcast does on ranks != src)
+r = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=3, batch_size=B))
+r.pool_alloc(3, 100, 80)
+o0 = ofdg.alloc_outputs(B, H, W)
+r.forward_counter(0, B, *o0); r.synchronize()      # (derived textures of the still empty pool)
+import ctypes as C
+ps, ns, pr, nr = C.c_void_p(), C.c_ulonglong(), C.c_void_p(), C.c_ulonglong()
+assert ofdg.lib().ofdg_pool_device(g.h, C.byref(ps), C.byref(ns), 0) == 0
+assert ofdg.lib().ofdg_pool_device(r.h, C.byref(pr), C.byref(nr), 1) == 0 and ns.value == nr.value == 3 * 100 * 80 * 4
+def view(p, n):
+    class Hd: pass
+    h = Hd(); h.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (p, False), "version": 2}
+    return torch.as_tensor(h, device="cuda")
+view(pr.value, nr.value).copy_(view(ps.value, ns.value)); torch.cuda.synchronize()
+assert np.array_equal(r.pool_download_all(), before)
+o2 = ofdg.alloc_outputs(B, H, W)
+r.forward_counter(0, B, *o2); r.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and not torch.equal(o0[0], o2[0])
+dist.destroy_process_group()
+print("ok")
+''' % root)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -646,7 +646,7 @@ import importlib, os, sys, numpy as np, torch
 import torch.distributed as dist
 sys.path.insert(0, %r)
 ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=0, world_size=1)
 W, H, B = 128, 96, 2
 g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=3, batch_size=B))
 g.pool_synthetic(3, 100, 80, 7)            # (smaller than 2W x 2H: the derived resized textures depend on the contents)
@@ -676,5 +676,9 @@ assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and not torch.equal(o0[0],
 dist.destroy_process_group()
 print("ok")
 ''' % root)
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    import socket
+    with socket.socket() as sk:          # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -211,6 +211,33 @@ def test_flow_loader_ring_yields_the_index_stream_in_order(ofdg):
         assert torch.equal(got[k][0], i0) and torch.equal(got[k][1], i1) and torch.equal(got[k][2], fl)
 
 
+def test_flow_loader_hands_batches_to_a_consumer_stream(ofdg):
+    """FlowLoader with a consumer stream of the caller's: the consumer's kernels (here: a running sum on that
+    stream, enqueued without any host synchronisation) see complete batches, and a buffer set is not re-rendered
+    before the consumer work that reads it has run - the sums equal those of isolated renders."""
+    import torch
+    W, H, B = 128, 96, 2
+    prm = ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=9, batch_size=B)
+    side = torch.cuda.Stream()
+    loader = ofdg.FlowLoader(prm, pool=lambda g: g.pool_synthetic(3, 256, 192, 2), prefetch=3, stream=side.cuda_stream)
+    sums = []
+    with torch.cuda.stream(side):
+        for k, (a, b, f) in zip(range(12), loader):
+            big = a.double().sum() + b.double().sum() * 3 + torch.nan_to_num(f.double()).sum() * 7   # (enqueued on `side`)
+            for _ in range(20):                      # keep the consumer busy while the ring renders ahead
+                big = big + (a.double() * 0).sum()
+            sums.append(big)
+    torch.cuda.synchronize()
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=9, batch_size=B))
+    g.pool_synthetic(3, 256, 192, 2)
+    o = ofdg.alloc_outputs(B, H, W)
+    for k in range(12):
+        g.forward_counter(k * B, B, *o)
+        g.synchronize()
+        want = o[0].double().sum() + o[1].double().sum() * 3 + torch.nan_to_num(o[2].double()).sum() * 7
+        assert float(sums[k]) == float(want), k
+
+
 def test_counter_sampler_has_room_for_the_worst_case_sample(ofdg):
     """32 objects per sample in mode 7 (BASELINE config 4): up to 7 outlines per object - the device sampler's
     per-sample outline slots must cover the worst case (no capacity error), at 1024x768."""

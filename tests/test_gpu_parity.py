@@ -682,3 +682,29 @@ print("ok")
         port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_end_to_end_fixture_on_the_gpu(ofdg, oracle):
+    """The committed end-to-end fixture (tests/golden/e2e_hashes.json, written by the oracle): the HIP path
+    renders the same scenes to the same bytes through the C-ABI - frames and flow, sha256 for sha256."""
+    import importlib.util, json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_e2e_goldens", os.path.join(here, "gen_e2e_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fix = json.load(open(os.path.join(here, "e2e_hashes.json")))
+    W, H = fix["size"]
+    B = fix["batch"]
+    pool = gen.pool()
+    for sc in fix["scenes"]:
+        mode, aa = sc["mode"], sc["use_antialiasing"]
+        g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=mode, use_antialiasing=aa))
+        g.pool_alloc(pool.shape[0], pool.shape[3], pool.shape[2])
+        for i in range(pool.shape[0]):
+            g.pool_upload(i, pool[i])
+        if mode == 9:
+            g.warp_upload(oracle.warp_crops(W, H, seed=5)[:4])
+        tasks, bps, n = ofdg.HostSampler(mode, W, H).next(B)
+        i0, i1, fl = render_gpu(ofdg, g, tasks, B, bps, n)
+        assert gen.digest(i0) == sc["image0"] and gen.digest(i1) == sc["image1"], (mode, aa)
+        assert gen.digest(fl) == sc["flow"], (mode, aa)

@@ -196,3 +196,19 @@ def test_background_prep_identity_is_the_centre_crop(oracle):
     same = oracle.render(p1, tasks, 2, bps, n, pool)
     for a, b in zip(base, same):
         assert np.array_equal(a, b)
+
+
+def test_end_to_end_fixture_pins_the_oracle(oracle):
+    """tests/golden/e2e_hashes.json (gen_e2e_goldens.py): the oracle renders the fixture's tiny scenes - six data
+    modes, antialiased and thresholded - to the bytes it rendered when the fixture was written (restatement drift)."""
+    import importlib.util, json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_e2e_goldens", os.path.join(here, "gen_e2e_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fix = json.load(open(os.path.join(here, "e2e_hashes.json")))
+    assert len(fix["scenes"]) == len(gen.SCENES) == 12
+    for sc in fix["scenes"]:
+        i0, i1, fl = gen.scene(sc["mode"], sc["use_antialiasing"])
+        assert gen.digest(i0) == sc["image0"] and gen.digest(i1) == sc["image1"], sc["mode"]
+        assert gen.digest(fl) == sc["flow"], sc["mode"]

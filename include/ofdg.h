@@ -214,6 +214,13 @@ int ofdg_forward_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
 int ofdg_sample_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
                         ofdg_task* tasks, ofdg_blueprint* bps);
 
+/* Checkpoint / resume of ofdg_forward: the number of batches this context has produced is its whole sampler
+ * state (the reference cannot resume: a restarted job replays its 45 streams from their seeds).
+ * ofdg_set_step(k) makes the next ofdg_forward produce batch k (counter sampler: at no cost; reference-stream
+ * sampler: the streams are rebuilt and k * batch_size * world_size tasks drawn and dropped on the host). */
+long long ofdg_get_step(const ofdg_ctx* ctx);
+int ofdg_set_step(ofdg_ctx* ctx, long long step);
+
 /* The internal stream the NEXT render / forward call of this context will work on
  * (a hipStream_t; they take turns).  See ofdg_render. */
 void* ofdg_stream(ofdg_ctx* ctx);

@@ -70,7 +70,7 @@ _lib = None
 EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
-    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream",
+    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
     "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
@@ -121,6 +121,9 @@ def lib():
         L.ofdg_forward.argtypes = [vp, vp, vp, vp, vp]
         L.ofdg_synchronize.argtypes = [vp, vp]
         L.ofdg_stream.argtypes = [vp]
+        L.ofdg_get_step.argtypes = [vp]
+        L.ofdg_get_step.restype = C.c_longlong
+        L.ofdg_set_step.argtypes = [vp, C.c_longlong]
         L.ofdg_stream.restype = vp
         L.ofdg_debug_rasterize.argtypes = [vp, vp, i32, vp]
         L.ofdg_debug_coverage.argtypes = [vp, i32, i32, i32, vp]
@@ -319,6 +322,15 @@ class Generator:
 
     def synchronize(self, stream=0):
         self._check(lib().ofdg_synchronize(self.h, C.c_void_p(stream)))
+
+    @property
+    def step(self):
+        """Batches produced by forward() so far = the sampler state to checkpoint."""
+        return int(lib().ofdg_get_step(self.h))
+
+    @step.setter
+    def step(self, k):
+        self._check(lib().ofdg_set_step(self.h, int(k)))
 
     def next_stream(self):
         """The internal hipStream_t (int) the next render / forward call works on; pass it as that call's

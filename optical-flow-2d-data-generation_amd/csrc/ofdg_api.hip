@@ -1049,6 +1049,28 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
                      d_flow, stream);
 }
 
+// Checkpoint / resume of ofdg_forward (the reference has none: a restarted job replays its streams from the
+// seeds): the step counter is the whole state.  Counter sampler: the next call renders the indices of `step`.
+// Reference-stream sampler: the 45 streams are rebuilt and step * batch_size * world_size tasks are drawn and
+// dropped (host, ~30 us per task).
+long long ofdg_get_step(const ofdg_ctx* c) { return c ? c->step : -1; }
+int ofdg_set_step(ofdg_ctx* c, long long step) {
+  if (!c || step < 0) return OFDG_EINVAL;
+  if (c->prm.sampler != OFDG_SAMPLER_COUNTER) {
+    const long long n = step * (long long)std::max(c->prm.batch_size, 1) * c->prm.world_size;
+    c->sampler.reset(new RefSampler(c->prm.mode, c->prm.width, c->prm.height, c->prm.num_objects));
+    std::vector<ofdg_blueprint> bps;
+    ofdg_task t;
+    for (long long i = 0; i < n; ++i) {
+      bps.clear();
+      int rc = c->sampler->next_task(&bps, &t, &c->err);
+      if (rc != OFDG_OK) return rc;
+    }
+  }
+  c->step = step;
+  return OFDG_OK;
+}
+
 int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   if (!c) return OFDG_EINVAL;
   HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));

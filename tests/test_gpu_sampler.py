@@ -380,3 +380,31 @@ np.savez(sys.argv[1], *[t.cpu().numpy() for o in outs for t in o])
     for other in results[1:]:
         for k in results[0].files:
             assert np.array_equal(results[0][k], other[k]), k
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_forward_resumes_from_a_step_counter(ofdg, sampler):
+    """Checkpoint / resume: a fresh context with step = k continues exactly where another one was after k
+    batches - reference streams (replayed on the host) and counter sampler alike, also per rank."""
+    import torch
+    W, H, B = 128, 96, 2
+    def make(rank=0, world=1):
+        g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=sampler, seed=5, batch_size=B, rank=rank, world_size=world))
+        g.pool_synthetic(3, 256, 192, 2)
+        return g
+    for rank, world in ((0, 1), (1, 2)):
+        g = make(rank, world)
+        outs = []
+        for k in range(5):
+            o = ofdg.alloc_outputs(B, H, W)
+            g.forward(*o)
+            outs.append(o)
+        g.synchronize()
+        assert g.step == 5
+        r = make(rank, world)
+        r.step = 3
+        for k in (3, 4):
+            o = ofdg.alloc_outputs(B, H, W)
+            r.forward(*o)
+            r.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[k])), (rank, k)

@@ -533,12 +533,15 @@ class FlowLoader:
     Use the tensors on the consumer stream, or synchronise before touching them elsewhere.  Samples shard
     over ranks by global index (params.rank / params.world_size): no communication."""
 
-    def __init__(self, params=None, pool=None, prefetch=3, stream=None, **kw):
+    def __init__(self, params=None, pool=None, prefetch=3, stream=None, start=0, **kw):
         import torch
         self.gen = Generator(params, **kw)
         p = self.gen.params
         if pool is not None:
             pool(self.gen)                      # callable that fills the texture pool (pool_synthetic / pool_upload ...)
+        if start:
+            self.gen.step = int(start)          # resume: the first batch handed out is batch `start` (see `consumed`)
+        self.start = int(start)
         if p.mode == 9 and self.gen.warp_count() == 0:
             self.gen.warp_generate(2, p.seed)
         self.prefetch = max(2, int(prefetch))
@@ -559,6 +562,11 @@ class FlowLoader:
             chain.wait_event(self.released[j])
         self.gen.forward(*self.bufs[j], s)
         self.ready[j].record(chain)
+
+    @property
+    def consumed(self):
+        """Index of the next batch the iterator will hand out: what to store in a checkpoint (`start=` on resume)."""
+        return self.start + self.k
 
     def __iter__(self):
         return self

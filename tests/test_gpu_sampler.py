@@ -211,6 +211,25 @@ def test_flow_loader_ring_yields_the_index_stream_in_order(ofdg):
         assert torch.equal(got[k][0], i0) and torch.equal(got[k][1], i1) and torch.equal(got[k][2], fl)
 
 
+def test_flow_loader_resumes_at_a_batch_index(ofdg):
+    """FlowLoader(start=k): the iterator continues with batch k of the stream (`consumed` is what a checkpoint stores)."""
+    import torch
+    W, H, B = 128, 96, 2
+    prm = ofdg.default_params(width=W, height=H, mode=5, sampler=1, seed=8, batch_size=B)
+    fill = lambda g: g.pool_synthetic(3, 256, 192, 2)
+    a = ofdg.FlowLoader(prm, pool=fill, prefetch=3)
+    ref = []
+    for k, o in zip(range(6), a):
+        torch.cuda.synchronize()
+        ref.append([t.clone() for t in o])
+    assert a.consumed == 6
+    b = ofdg.FlowLoader(prm, pool=fill, prefetch=4, start=4)
+    for k, o in zip((4, 5), b):
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(o, ref[k]))
+    assert b.consumed == 6
+
+
 def test_flow_loader_hands_batches_to_a_consumer_stream(ofdg):
     """FlowLoader with a consumer stream of the caller's: the consumer's kernels (here: a running sum on that
     stream, enqueued without any host synchronisation) see complete batches, and a buffer set is not re-rendered

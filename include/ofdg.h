@@ -262,6 +262,10 @@ int ofdg_debug_item_count(ofdg_ctx* ctx);
  * [u*256+v] (DG:606, 626), AA mask byte [c], draw_image blend [d*256+m] for s=s_fixed. */
 int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl,
                       uint8_t* blend_tbl, int s_fixed);
+/* include/ofdg_detmath.h (the sin / cos / expf the device counter-sampler path is defined with) evaluated
+ * on the device: n angles -> sin, cos; m floats -> expf.  Host arrays. */
+int ofdg_debug_detmath(ofdg_ctx* ctx, const double* angles, int n, double* sin_out, double* cos_out,
+                       const float* x, int m, float* expf_out);
 int ofdg_set_profiling(ofdg_ctx* ctx, int enabled);
 int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
 

@@ -71,7 +71,7 @@ EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
-    "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables",
+    "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables", "ofdg_debug_detmath",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
@@ -129,6 +129,7 @@ def lib():
         L.ofdg_debug_coverage.argtypes = [vp, i32, i32, i32, vp]
         L.ofdg_debug_num_shapes.argtypes = [vp, i32]
         L.ofdg_debug_tables.argtypes = [vp, vp, vp, vp, vp, i32]
+        L.ofdg_debug_detmath.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
         L.ofdg_set_profiling.argtypes = [vp, i32]
         L.ofdg_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
         L.ofdg_forward_counter.argtypes = [vp, C.c_longlong, i32, vp, vp, vp, vp]
@@ -388,6 +389,17 @@ class Generator:
         self._check(lib().ofdg_debug_tables(self.h, add.ctypes.data_as(vp), sub.ctypes.data_as(vp), aa.ctypes.data_as(vp),
                                             bl.ctypes.data_as(vp), s_fixed))
         return add, sub, aa, bl
+
+    def debug_detmath(self, angles, x):
+        """include/ofdg_detmath.h evaluated on the device: (sin, cos) of float64 angles, expf of float32 x."""
+        import numpy as np
+        a = np.ascontiguousarray(angles, np.float64)
+        x = np.ascontiguousarray(x, np.float32)
+        s, c, e = np.zeros_like(a), np.zeros_like(a), np.zeros_like(x)
+        vp = C.c_void_p
+        self._check(lib().ofdg_debug_detmath(self.h, a.ctypes.data_as(vp), len(a), s.ctypes.data_as(vp), c.ctypes.data_as(vp),
+                                             x.ctypes.data_as(vp), len(x), e.ctypes.data_as(vp)))
+        return s, c, e
 
     def set_profiling(self, mode=2):
         self._check(lib().ofdg_set_profiling(self.h, int(mode)))

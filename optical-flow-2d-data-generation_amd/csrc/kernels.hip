@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/ofdg_detmath.h"
 #include "ofdg_device.h"
 #include "warpfields.h"
 
@@ -1310,7 +1311,8 @@ __global__ __launch_bounds__(256) void wf_sample_kernel(const DevDisplacer* __re
     const float rx = D.a * (x - D.scx) + D.b * (y - D.scy);
     const float ry = (D.c * (x - D.scx) + D.d * (y - D.scy)) * D.ratio_x_y;
     const float dist_sq = rx * rx + ry * ry;
-    const float w = D.normalizer * (D.gauss_prefactor * expf(-dist_sq / D.two_sigma_sq));
+    // (expf = ofdg_det_expf: the fp64 value rounded once, the same on the device and in the oracle)
+    const float w = D.normalizer * (D.gauss_prefactor * ofdg_det_expf(-dist_sq / D.two_sigma_sq));
     fu += u * w; fv += v * w;
     iu += ju * w; iv += jv * w;
   }
@@ -1574,6 +1576,14 @@ __global__ __launch_bounds__(256) void pool_resize_axis_kernel(const uint32_t* _
     }
     dst[i] = out;
   }
+}
+
+// include/ofdg_detmath.h evaluated on the device (tests: device == host bit for bit)
+__global__ void detmath_kernel(const double* __restrict__ a, int n, double* __restrict__ s, double* __restrict__ c,
+                               const float* __restrict__ x, int m, float* __restrict__ e) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ofdg_det_sincos(a[i], s + i, c + i);
+  if (i < m) e[i] = ofdg_det_expf(x[i]);
 }
 
 // exhaustive probe of the per-byte device formulas (tests): tables of 65536 entries

@@ -1336,4 +1336,25 @@ int ofdg_debug_tables(ofdg_ctx* c, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* 
   return OFDG_OK;
 }
 
+// include/ofdg_detmath.h on the device: n angles -> sin, cos; m floats -> expf (host arrays)
+int ofdg_debug_detmath(ofdg_ctx* c, const double* angles, int n, double* sin_out, double* cos_out, const float* x, int m, float* expf_out) {
+  if (!c || n < 0 || m < 0 || (n > 0 && (!angles || !sin_out || !cos_out)) || (m > 0 && (!x || !expf_out))) return OFDG_EINVAL;
+  double* d = nullptr;
+  float* f = nullptr;
+  const int k = std::max(std::max(n, m), 1);
+  HIP_OK(c, hipMalloc((void**)&d, (size_t)3 * k * sizeof(double)));
+  HIP_OK(c, hipMalloc((void**)&f, (size_t)2 * k * sizeof(float)));
+  if (n) HIP_OK(c, hipMemcpy(d, angles, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  if (m) HIP_OK(c, hipMemcpy(f, x, (size_t)m * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(detmath_kernel, dim3((k + 255) / 256), dim3(256), 0, 0, d, n, d + k, d + 2 * k, f, m, f + k);
+  HIP_OK(c, hipGetLastError());
+  if (n) {
+    HIP_OK(c, hipMemcpy(sin_out, d + k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(c, hipMemcpy(cos_out, d + 2 * k, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (m) HIP_OK(c, hipMemcpy(expf_out, f + k, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipFree(d)); HIP_OK(c, hipFree(f));
+  return OFDG_OK;
+}
+
 }  // extern "C"

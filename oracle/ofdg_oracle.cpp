@@ -686,6 +686,13 @@ int ofdg_oracle_shape_masks(const ofdg_params* prm, const ofdg_task* task, const
   return (int)scene.shape_order.size();
 }
 
+// 0 (default): libm, the reference's arithmetic; 1: include/ofdg_detmath.h (the device counter-sampler path's
+// definition of sin / cos / expf).  Process-wide; returns the previous value.
+int ofdg_oracle_set_detmath(int on) { const int old = detmath_flag(); detmath_flag() = on ? 1 : 0; return old; }
+// the functions themselves (CPU tests: accuracy against libm; GPU tests: device == host bit for bit)
+void ofdg_oracle_det_sincos(const double* a, int n, double* s, double* c) { for (int i = 0; i < n; ++i) ofdg_det_sincos(a[i], s + i, c + i); }
+void ofdg_oracle_det_expf(const float* x, int n, float* y) { for (int i = 0; i < n; ++i) y[i] = ofdg_det_expf(x[i]); }
+
 int ofdg_oracle_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 
 // the record of the background preparation chain (test hook; same layout as ofdg_host_bg_prep)

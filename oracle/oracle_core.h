@@ -20,7 +20,15 @@
 #include <cstring>
 #include <vector>
 
+#include "../include/ofdg_detmath.h"
+
 namespace oracle {
+
+// Which elementary functions build the affines (and the Gaussian supports of mode 9):
+// 0 = the host libm, as the reference does (reference-stream path); 1 = ofdg_det_* of
+// include/ofdg_detmath.h, the functions the DEVICE counter-sampler path is defined with (that path
+// has no reference bit stream; see the header).  Set by ofdg_oracle_set_detmath().
+inline int& detmath_flag() { static int f = 0; return f; }
 
 // ---------------------------------------------------------------------------
 // agg::trans_affine (AGG 2.4 agg_trans_affine.h / .cpp), used at
@@ -31,7 +39,14 @@ struct Affine {
   Affine() {}
   Affine(double a, double b, double c, double d, double e, double f)
       : sx(a), shy(b), shx(c), sy(d), tx(e), ty(f) {}
-  static Affine rotation(double a) { return Affine(std::cos(a), std::sin(a), -std::sin(a), std::cos(a), 0.0, 0.0); }
+  static Affine rotation(double a) {
+    if (detmath_flag()) {
+      double s, c;
+      ofdg_det_sincos(a, &s, &c);
+      return Affine(c, s, -s, c, 0.0, 0.0);
+    }
+    return Affine(std::cos(a), std::sin(a), -std::sin(a), std::cos(a), 0.0, 0.0);
+  }
   static Affine scaling(double s) { return Affine(s, 0.0, 0.0, s, 0.0, 0.0); }
   static Affine translation(double x, double y) { return Affine(1.0, 0.0, 0.0, 1.0, x, y); }
   Affine& multiply(const Affine& m) {

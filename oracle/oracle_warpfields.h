@@ -14,6 +14,8 @@
 #include <random>
 #include <vector>
 
+#include "oracle_core.h"
+
 namespace oracle {
 
 // CImg<unsigned char>::linear_atXY(fx,fy,0,c,out_value=0) -> (unsigned char) (Dirichlet).
@@ -168,7 +170,8 @@ struct Gaussian2D {  // WF:88-112
     const float rx = a * (x - cx) + b * (y - cy);
     const float ry = (c * (x - cx) + d * (y - cy)) * ratio_x_y;
     const float dist_sq{rx * rx + ry * ry};
-    return gauss_prefactor * std::exp(-dist_sq / (2 * sigma_sq));
+    const float arg = -dist_sq / (2 * sigma_sq);
+    return gauss_prefactor * (detmath_flag() ? ofdg_det_expf(arg) : std::exp(arg));
   }
   float at(float x, float y) const { return normalizer * raw_at(x, y); }
 };

@@ -96,8 +96,36 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ofdg_oracle_shape_masks.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ofdg_oracle_set_detmath.argtypes = [C.c_int]
+        L.ofdg_oracle_det_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ofdg_oracle_det_expf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
+
+
+class detmath:
+    """Context manager: the oracle builds its affines / Gaussian supports with include/ofdg_detmath.h (what the
+    device counter-sampler path is defined with) instead of libm (the reference's arithmetic, default)."""
+
+    def __enter__(self):
+        self.old = lib().ofdg_oracle_set_detmath(1)
+
+    def __exit__(self, *a):
+        lib().ofdg_oracle_set_detmath(self.old)
+
+
+def det_sincos(a):
+    a = np.ascontiguousarray(a, np.float64)
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    lib().ofdg_oracle_det_sincos(_ptr(a), len(a), _ptr(s), _ptr(c))
+    return s, c
+
+
+def det_expf(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    lib().ofdg_oracle_det_expf(_ptr(x), len(x), _ptr(y))
+    return y
 
 
 def _ptr(a):

@@ -271,3 +271,38 @@ def test_background_prep_record_equals_oracle(ofdg, oracle):
     # identity parameters: the centre crop, unit steps
     assert fp(300, 200, 64, 48, 0.0, 1.0, 0, 0, *a) == 0
     assert list(a[0])[:2] == [1.0, 0.0] and list(a[0])[6:] == [1.0, 1.0] and list(a[1]) == [86, 52, 128, 96, 0, 0]
+
+
+# ---- include/ofdg_detmath.h: the functions the device counter-sampler path is defined with ----
+def test_detmath_is_within_one_ulp_of_libm(oracle):
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.uniform(-8, 8, 400000), rng.uniform(-8, 8, 400000).astype(np.float32).astype(np.float64),
+                        rng.uniform(-2000, 2000, 100000), [0.0, -0.0, math.pi, -math.pi, math.pi / 2, math.pi / 4, 1e-30, 1e-300]])
+    s, c = oracle.det_sincos(a)
+    def ulps(x, y):
+        xi, yi = x.view(np.int64), y.view(np.int64)
+        xi = np.where(xi < 0, np.int64(-2**63) - xi, xi); yi = np.where(yi < 0, np.int64(-2**63) - yi, yi)
+        return np.abs(xi - yi)
+    assert ulps(s, np.sin(a)).max() <= 1 and ulps(c, np.cos(a)).max() <= 1
+    assert (ulps(s, np.sin(a)) > 0).mean() < 0.05
+    assert s[-8] == 0.0 and c[-8] == 1.0 and np.isnan(oracle.det_sincos([1e9, np.inf, np.nan])[0]).all()
+    x = np.concatenate([rng.uniform(-104, 12, 500000), [0.0, -0.0, -200.0, 100.0]]).astype(np.float32)
+    e = oracle.det_expf(x)
+    want = np.exp(x.astype(np.float64)).astype(np.float32)           # fp64 exp rounded once
+    assert (np.abs(e.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)) > 1).sum() == 0
+    assert (e != want).mean() < 1e-6 and e[-4] == 1.0 and e[-3] == 1.0 and e[-2] == 0.0 and np.isinf(e[-1])
+
+
+def test_oracle_detmath_switch_only_touches_the_last_bit(oracle):
+    """oracle.detmath(): same scene, affines from include/ofdg_detmath.h instead of libm - a handful of pixels may
+    flip (that is why the device path is DEFINED with these functions), nothing else changes."""
+    W, H = 128, 96
+    tasks, bps, n = oracle.Sampler(7, W, H).next(2, cap=600)
+    pool = np.random.default_rng(0).integers(0, 256, (2, 3, 2 * H, 2 * W), np.uint8)
+    a = oracle.render(oracle.default_params(W, H, 7), tasks, 2, bps, n, pool)
+    with oracle.detmath():
+        b = oracle.render(oracle.default_params(W, H, 7), tasks, 2, bps, n, pool)
+    c = oracle.render(oracle.default_params(W, H, 7), tasks, 2, bps, n, pool)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, z)                                   # the switch is restored
+        assert (x != y).mean() < 1e-2

@@ -217,7 +217,8 @@ int ofdg_sample_counter(ofdg_ctx* ctx, long long first_index, int n_samples,
 /* Checkpoint / resume of ofdg_forward: the number of batches this context has produced is its whole sampler
  * state (the reference cannot resume: a restarted job replays its 45 streams from their seeds).
  * ofdg_set_step(k) makes the next ofdg_forward produce batch k (counter sampler: at no cost; reference-stream
- * sampler: the streams are rebuilt and k * batch_size * world_size tasks drawn and dropped on the host). */
+ * sampler: the streams are rebuilt and k * batch_size * world_size tasks drawn and dropped on the host; mode 9:
+ * the crop serving order of this rank is replayed too - install the warp fields BEFORE calling it). */
 long long ofdg_get_step(const ofdg_ctx* ctx);
 int ofdg_set_step(ofdg_ctx* ctx, long long step);
 

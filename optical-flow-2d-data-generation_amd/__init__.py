@@ -551,11 +551,11 @@ class FlowLoader:
         p = self.gen.params
         if pool is not None:
             pool(self.gen)                      # callable that fills the texture pool (pool_synthetic / pool_upload ...)
-        if start:
-            self.gen.step = int(start)          # resume: the first batch handed out is batch `start` (see `consumed`)
-        self.start = int(start)
         if p.mode == 9 and self.gen.warp_count() == 0:
             self.gen.warp_generate(2, p.seed)
+        if start:                               # (after the warp fields: resuming replays the crop serving order too)
+            self.gen.step = int(start)          # resume: the first batch handed out is batch `start` (see `consumed`)
+        self.start = int(start)
         self.prefetch = max(2, int(prefetch))
         self.consumer = torch.cuda.current_stream() if stream is None else torch.cuda.ExternalStream(int(stream))
         self.bufs = [alloc_outputs(p.batch_size, p.height, p.width) for _ in range(self.prefetch)]

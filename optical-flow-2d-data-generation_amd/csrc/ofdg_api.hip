@@ -190,6 +190,13 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = "width must be a multiple of 8 and height even";
     return OFDG_EINVAL;
   }
+  {  // a sample holds at most 64 foreground objects (bits of a block mask); the device sampler generates at most 32
+    const int cap = params->sampler == OFDG_SAMPLER_COUNTER ? kCsMaxObjects : kMaxFgObjects;
+    if (params->num_objects < 0 || params->num_objects > cap) {
+      g_create_error = "num_objects must be 0 (reference: 16..23) or 1.." + std::to_string(cap) + " for this sampler";
+      return OFDG_EINVAL;
+    }
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1031,8 +1038,9 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
     const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
     if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
     const long long first = c->step * (long long)B * world + (long long)rank * B;
-    c->step++;
-    return ofdg_forward_counter(c, first, B, d_img0, d_img1, d_flow, stream);
+    const int rc = ofdg_forward_counter(c, first, B, d_img0, d_img1, d_flow, stream);
+    if (rc == OFDG_OK) c->step++;  // (a failed call does not advance the checkpoint counter)
+    return rc;
   }
   const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
   if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
@@ -1044,15 +1052,19 @@ int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void*
     int rc = c->sampler->next_task(&c->fw_bps, &c->fw_tasks[i], &c->err);
     if (rc != OFDG_OK) return rc;
   }
-  c->step++;
-  return ofdg_render(c, c->fw_tasks.data() + (size_t)rank * B, B, c->fw_bps.data(), (int)c->fw_bps.size(), d_img0, d_img1,
-                     d_flow, stream);
+  const int rc = ofdg_render(c, c->fw_tasks.data() + (size_t)rank * B, B, c->fw_bps.data(), (int)c->fw_bps.size(), d_img0, d_img1,
+                             d_flow, stream);
+  // the streams have moved on either way; the batch counts once it is in flight
+  if (rc == OFDG_OK) c->step++;
+  else ofdg_set_step(c, c->step);  // rewind the streams (and the crop server) to the start of this batch
+  return rc;
 }
 
 // Checkpoint / resume of ofdg_forward (the reference has none: a restarted job replays its streams from the
 // seeds): the step counter is the whole state.  Counter sampler: the next call renders the indices of `step`.
 // Reference-stream sampler: the 45 streams are rebuilt and step * batch_size * world_size tasks are drawn and
-// dropped (host, ~30 us per task).
+// dropped (host, ~30 us per task); in mode 9 the crop server (CropGenerator::get_crop's serving order, WF:516-538)
+// is replayed as well: one crop per deforming background / top-level object of THIS rank's tasks.
 long long ofdg_get_step(const ofdg_ctx* c) { return c ? c->step : -1; }
 int ofdg_set_step(ofdg_ctx* c, long long step) {
   if (!c || step < 0) return OFDG_EINVAL;
@@ -1061,10 +1073,18 @@ int ofdg_set_step(ofdg_ctx* c, long long step) {
     c->sampler.reset(new RefSampler(c->prm.mode, c->prm.width, c->prm.height, c->prm.num_objects));
     std::vector<ofdg_blueprint> bps;
     ofdg_task t;
+    const int B = std::max(c->prm.batch_size, 1), world = c->prm.world_size, rank = c->prm.rank;
+    const bool crops = c->prm.mode == 9 && c->crop_server.n_crops > 0;
+    if (crops) { c->crop_server.head = 0; c->crop_server.counter = 0; }
     for (long long i = 0; i < n; ++i) {
       bps.clear();
       int rc = c->sampler->next_task(&bps, &t, &c->err);
       if (rc != OFDG_OK) return rc;
+      if (crops && (i / B) % world == rank) {  // realize_batch serves one crop per deforming background / object
+        if (bps[t.background].do_warpfield_deformation) (void)c->crop_server.get();
+        for (int k = 0; k < t.n_objects; ++k)
+          if (bps[t.first_object + k].do_warpfield_deformation) (void)c->crop_server.get();
+      }
     }
   }
   c->step = step;

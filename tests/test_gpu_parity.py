@@ -422,22 +422,45 @@ def test_mode9_render_matches_oracle_with_uploaded_crops(ofdg, oracle, use_aa):
     assert np.array_equal(r0, e0) and not np.array_equal(r1, e1) and not np.array_equal(np.nan_to_num(rf), np.nan_to_num(ef))
 
 
-def test_mode9_field_generation_close_to_oracle(ofdg, oracle):
-    """Device warp-field generation (63-displacer analogue at small size, 17 self-composition
-    passes) vs the oracle: same seeded displacers; libm's expf differs in the last ulp
-    between host and device, so fields agree to a tolerance, not bitwise."""
+def test_mode9_field_generation_equals_oracle(ofdg, oracle):
+    """Device warp-field generation (displacer sampling, 17 self-composition passes, NaN flags, clamp, crops;
+    WarpFields.cpp:337-455, 617-633) vs the oracle on the same seeded displacers.  The Gaussian weight's expf is
+    ofdg_det_expf on both sides (include/ofdg_detmath.h): every float of every crop is identical, NaN pattern included."""
     W, H = 128, 96
     g = make_gen(ofdg, W, H, 9, pool=(2, 256, 192))
     g.warp_generate(1, seed=11)
-    ref = oracle.warp_crops(W, H, seed=11)
+    with oracle.detmath():
+        ref = oracle.warp_crops(W, H, seed=11)
     assert g.warp_count() == len(ref)
-    worst = 0.0
-    for k in range(0, len(ref), 7):
+    for k in range(len(ref)):
         c = g.warp_download(k)
-        assert np.array_equal(np.isnan(c), np.isnan(ref[k])) or (np.isnan(c) != np.isnan(ref[k])).mean() < 1e-3
-        ok = ~np.isnan(c) & ~np.isnan(ref[k])
-        worst = max(worst, float(np.abs(c[ok] - ref[k][ok]).max()))
-    assert worst < 2e-2, worst     # displacements are tens of pixels; agreement is ~1e-4 px
+        assert np.array_equal(c.view(np.int32), ref[k].view(np.int32)), k
+    assert np.isnan(ref).any() or np.abs(ref).max() > 1.0
+
+
+def test_mode9_full_size_device_generated_fields_match_oracle(ofdg, oracle):
+    """BASELINE config 3 at its own size (mode 9, 512 x 384): the 1536^2 big field generated on the device equals the
+    oracle's bit for bit (all 40 crops), and samples rendered with the DEVICE-generated crops (downloaded and handed
+    to the oracle) match at 0 LSB / 0 ULP."""
+    W, H, B = 512, 384, 3
+    g = make_gen(ofdg, W, H, 9, num_objects=16, pool=(4, 1024, 768))
+    g.warp_generate(1, seed=3)
+    crops = np.stack([g.warp_download(k) for k in range(g.warp_count())])
+    with oracle.detmath():
+        ref = oracle.warp_crops(W, H, seed=3)
+    assert np.array_equal(crops.view(np.int32), ref.view(np.int32))
+    pool = g.pool_download_all()
+    s = oracle.Sampler(9, W, H, 16)
+    for _ in range(4):                      # skip ahead to a batch with deforming objects and backgrounds
+        tasks, bps, n = s.next(B)
+    deform = sum(1 for t in tasks for i in range(t.n_objects) if bps[t.first_object + i].do_warpfield_deformation) + \
+        sum(1 for t in tasks if bps[t.background].do_warpfield_deformation)
+    assert deform >= 3, deform
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    e0, e1, ef = oracle.render(oracle.default_params(W, H, 9), tasks, B, bps, n, pool, warp_crops=crops, reuse=2)
+    assert np.array_equal(got[0], e0)
+    assert np.array_equal(got[1], e1), "image1 differs at %d px" % (got[1] != e1).sum()
+    assert nan_equal_ulp(got[2], ef) == 0
 
 
 def test_mode9_full_size_generated_fields(ofdg):

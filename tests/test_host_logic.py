@@ -168,6 +168,15 @@ def test_prototxt_parser(ofdg):
         ofdg.parse_prototxt(PROTOTXT[:-4])  # missing closing brace
 
 
+def test_create_rejects_object_counts_the_sampler_cannot_hold(ofdg):
+    """num_objects beyond what a sample record holds is an error, not a silent clamp: 32 for the device counter
+    sampler, 64 for the reference-stream sampler (checked before any device is touched)."""
+    for sampler, bad in ((1, 33), (0, 65), (0, -1)):
+        with pytest.raises(ofdg.OfdgError) as e:
+            ofdg.Generator(ofdg.default_params(mode=7, sampler=sampler, num_objects=bad))
+        assert e.value.code == ofdg.EINVAL and "num_objects" in str(e.value)
+
+
 def test_no_gpu_means_loud_failure(ofdg):
     import torch
     if torch.cuda.is_available():

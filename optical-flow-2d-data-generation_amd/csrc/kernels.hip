@@ -1280,6 +1280,442 @@ __global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
 }
 
 // --------------------------------------------------------------------------
+// compose_rigid_kernel: the compose kernel of the rigid modes (every mode but 9), written around the
+// latency of a strip: what a wave waits for is fetched in as few dependent round trips as the data allows.
+//   scalar stage 1   sample record (background matrices inline) + the block's object masks   [kernel arguments are
+//                    preloaded into SGPRs: leading scalar parameters, -amdgpu-kernarg-preload-count]
+//   scalar stage 2   headers (coverage slot, texture origin, kind) of the first kPre objects of the mask
+//   vector stage 1   background texels of both frames, coverage of those objects, their full records (lane i reads
+//                    dword i; the matrices are moved to SGPRs with v_readlane when the visit needs them)
+//   per visit        texture taps of both frames (one round trip), blend, flow
+//   stores           8 fp32 planes, 16-byte non-temporal stores
+// Same arithmetic as compose_tile (the mode-9 kernels), bit for bit.
+// --------------------------------------------------------------------------
+// a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+struct Taps4 {
+  uint2 t0[kPx], t1[kPx];  // texel pairs of the two rows (mode 2: t0[p].x = the finished pixel)
+  uint32_t xf, yf;         // fractions, byte p = pixel p
+  int mode;                // 0 paired loads, 1 reflected single loads, 2 general interpolator (nothing issued)
+};
+// first half of sample4<true>: addresses + loads
+__device__ __forceinline__ Taps4 taps_issue(const uint32_t* __restrict__ tex_, const WarpGeom& g, const RowDDA& R, int i0, bool need) {
+  const uint32_t* __restrict__ tex = uniform_ptr(tex_);
+  Taps4 T;
+  int xh[kPx], yh[kPx];
+  {
+    int ax = (i0 + 1) * R.rx + g.tw - 1, bx = R.x1 - 129 + i0 * R.lx;  // dda_at(...) - 128
+    int ay = (i0 + 1) * R.ry + g.tw - 1, by = R.y1 - 129 + i0 * R.ly;
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) {
+      xh[p] = bx + (ax >> g.nshift); yh[p] = by + (ay >> g.nshift);
+      ax += R.rx; bx += R.lx; ay += R.ry; by += R.ly;
+    }
+  }
+  T.xf = ((uint32_t)xh[0] & 255u) | (((uint32_t)xh[1] & 255u) << 8) | (((uint32_t)xh[2] & 255u) << 16) | ((uint32_t)xh[3] << 24);
+  T.yf = ((uint32_t)yh[0] & 255u) | (((uint32_t)yh[1] & 255u) << 8) | (((uint32_t)yh[2] & 255u) << 16) | ((uint32_t)yh[3] << 24);
+  const bool in_range = (unsigned)(xh[0] >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(xh[kPx - 1] >> 8) <= (unsigned)(g.tw - 2) &&
+                        (unsigned)(yh[0] >> 8) <= (unsigned)(g.th - 2) && (unsigned)(yh[kPx - 1] >> 8) <= (unsigned)(g.th - 2);
+  if (__ballot(need && !in_range) == 0ull) {
+    T.mode = 0;
+    const char* base = reinterpret_cast<const char*>(tex);
+    const char* base1 = uniform_ptr(base + (size_t)g.pitch * 4u);
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) {
+      const uint32_t off = need ? ((uint32_t)(yh[p] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[p] >> 8)) * 4u : 0u;
+      T.t0[p] = *reinterpret_cast<const uint2*>(base + off);
+      T.t1[p] = *reinterpret_cast<const uint2*>(base1 + off);
+    }
+  } else {
+    const int tw2 = g.tw2, th2 = g.th2;
+    bool one_period = true;
+#pragma unroll
+    for (int p = 0; p < kPx; p += kPx - 1)
+      one_period = one_period && (unsigned)((xh[p] >> 8) + tw2) < 3u * (unsigned)tw2 - 1u && (unsigned)((yh[p] >> 8) + th2) < 3u * (unsigned)th2 - 1u;
+    if (__ballot(need && !one_period) == 0ull) {
+      T.mode = 1;
+      auto reflect = [](int v, int size, int size2) {  // wrap_mode_reflect for -size2 <= v < 2 * size2
+        int m = v < 0 ? v + size2 : v;
+        m = m >= size2 ? m - size2 : m;
+        return m >= size ? size2 - 1 - m : m;
+      };
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        const int xl = need ? xh[p] >> 8 : 0, yl = need ? yh[p] >> 8 : 0;
+        const uint32_t xa = (uint32_t)reflect(xl, g.tw, tw2), xb = (uint32_t)reflect(xl + 1, g.tw, tw2);
+        const uint32_t ra = (uint32_t)reflect(yl, g.th, th2) * (uint32_t)g.pitch, rb = (uint32_t)reflect(yl + 1, g.th, th2) * (uint32_t)g.pitch;
+        const char* base = reinterpret_cast<const char*>(tex);
+        T.t0[p] = make_uint2(*reinterpret_cast<const uint32_t*>(base + (ra + xa) * 4u), *reinterpret_cast<const uint32_t*>(base + (ra + xb) * 4u));
+        T.t1[p] = make_uint2(*reinterpret_cast<const uint32_t*>(base + (rb + xa) * 4u), *reinterpret_cast<const uint32_t*>(base + (rb + xb) * 4u));
+        __builtin_amdgcn_sched_barrier(0);  // one pixel's addresses at a time: this (rare) path must not set the kernel's register count
+      }
+    } else {
+      T.mode = 2;  // absurd motions only: the general interpolator, pixel by pixel, right here
+      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // (a rolled loop and selects: this path must not set the kernel's register count)
+#pragma unroll 1
+      for (int p = 0; p < kPx; ++p) {
+        const uint32_t v = sample_bilinear<true>(tex, g, R, i0 + p);
+        r0 = p == 0 ? v : r0; r1 = p == 1 ? v : r1; r2 = p == 2 ? v : r2; r3 = p == 3 ? v : r3;
+      }
+      T.t0[0] = make_uint2(r0, 0); T.t0[1] = make_uint2(r1, 0); T.t0[2] = make_uint2(r2, 0); T.t0[3] = make_uint2(r3, 0);
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) T.t1[p] = make_uint2(0, 0);
+    }
+  }
+  return T;
+}
+__device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
+  if (T.mode == 2) {  // (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) out[p] = T.t0[p].x;
+  } else {
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) out[p] = bilerp_rgb(T.t0[p], T.t1[p], (T.xf >> (8 * p)) & 255u, (T.yf >> (8 * p)) & 255u);
+  }
+}
+
+#if !defined(OFDG_X_STORE) || OFDG_X_STORE == 0
+#define OFDG_STORE(v, p) __builtin_nontemporal_store(v, p)
+#elif OFDG_X_STORE == 1
+#define OFDG_STORE(v, p) (*(p) = (v))
+#elif OFDG_X_STORE == 2
+#define OFDG_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory")
+#elif OFDG_X_STORE == 3
+#define OFDG_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory")
+#elif OFDG_X_STORE == 4
+#define OFDG_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory")
+#endif
+#ifndef OFDG_X_PRE
+#define OFDG_X_PRE 2
+#endif
+constexpr int kPre = OFDG_X_PRE;  // objects of a block whose header / coverage / record are fetched ahead of their visit
+
+template <bool kPow2>
+__device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
+                                              const DevObject* __restrict__ objects, const uint8_t* __restrict__ cov,
+                                              int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+                                              const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
+                                              float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+                                              const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+  static_assert(kPx == 4, "mask bytes are packed four to a word");
+  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // raster_kernel has consumed the work list
+  // XCD-aware strip mapping (see compose_body)
+  int wg = blockIdx.x;
+  if (wg < (n_strips & ~255)) {
+    const int xcd = wg & 7, slot = wg >> 3;
+    wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31);
+  }
+  const int tile = wg >> 2, sub = wg & 3;
+  const int tiles = tiles_x * tiles_y;
+  const int s = tile / tiles;
+  const int t = tile - s * tiles;
+  const int trow = t / tiles_x;
+  const int ty0 = trow * kTileH, tx0 = (t - trow * tiles_x) * kTileW;
+  const int lane = (int)threadIdx.x;
+  const int x0 = tx0 + (lane & 15) * kPx;
+  const int y = ty0 + sub * 4 + (lane >> 4);
+  const bool inside = (x0 < W) && (y < H);
+
+  // ---- scalar stage 1: sample (+ background) record, block masks ----
+  const DevSample smp = samples[s];
+  unsigned long long mask0, mask1;
+  {
+    const int nby = (H + kBandRows - 1) / kBandRows;
+    const int brow = (ty0 + (sub >> 1) * kBandRows) / kBandRows;
+    const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(blockmask + ((size_t)(s * nby + min(brow, nby - 1)) * tiles_x + tx0 / kTileW) * 2);
+    mask0 = mm.x; mask1 = mm.y;
+  }
+  unsigned long long omask = mask0 | mask1;
+  const DevObject* objs = objects + smp.first_object;
+  const uint32_t pix = (uint32_t)(y * W + x0);
+  const size_t slot_bytes = (size_t)W * H;
+
+  // ---- scalar stage 2: outline slots of the first kPre objects of the mask (sample record: scalar-cache hits) ----
+  const uint32_t* shape_tab = reinterpret_cast<const uint32_t*>(samples[s].shape_of);
+  auto shape_entry = [&](int oi) -> uint32_t {  // oi >= 1; two 16-bit entries per dword
+    const uint32_t w = shape_tab[(oi - 1) >> 1];
+    return ((oi - 1) & 1) ? (w >> 16) : (w & 0xFFFFu);
+  };
+  int pre_oi[kPre];
+  uint32_t pre_sh[kPre];
+  {
+    unsigned long long m = omask;
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      pre_oi[k] = m ? __ffsll((long long)m) : 0;
+      m &= m - 1;  // (0 stays 0)
+      pre_sh[k] = pre_oi[k] ? shape_entry(pre_oi[k]) : (uint32_t)kShapeComposite;
+    }
+  }
+
+  // ---- vector stage 1: background texels, coverage + records of the first kPre objects ----
+  WarpGeom gb;
+  gb.tw = 2 * W; gb.th = 2 * H; gb.tw2 = 4 * W; gb.th2 = 4 * H;
+  gb.mx2 = ((gb.tw2 & (gb.tw2 - 1)) == 0) ? gb.tw2 - 1 : -1;
+  gb.my2 = ((gb.th2 & (gb.th2 - 1)) == 0) ? gb.th2 - 1 : -1;
+  gb.nshift = ((gb.tw & (gb.tw - 1)) == 0) ? (31 - __clz(gb.tw)) : -1;
+  gb.pitch = bg_pitch;
+  const uint32_t* btex = bgpool + smp.bg_tex_base;
+  const int yy = y + H / 2, xx = x0 + W / 2;
+  uint4 bq = make_uint4(0, 0, 0, 0);
+  RowDDA Rb;
+  Taps4 Tb;
+  if (inside) {
+    bq = *reinterpret_cast<const uint4*>(btex + (uint32_t)(yy * gb.pitch + xx));  // frame 0: identity warp == copy (DG:667-668, 680)
+    Rb = make_row<kPow2>(smp.bg_tex_inv, yy, gb.tw, gb.nshift);
+  } else {
+    Rb = RowDDA{0, 0, 1, 0, 0, 1};
+  }
+  if constexpr (kPow2) Tb = taps_issue(btex, gb, Rb, xx, inside);
+  uint32_t pre_c0[kPre], pre_c1[kPre], pre_rec[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    pre_c0[k] = 0; pre_c1[k] = 0; pre_rec[k] = 0;
+    if (!(pre_sh[k] & kShapeComposite)) {  // a simple object (wave-uniform)
+      const uint8_t* c = cov + (size_t)(smp.first_shape + (int)pre_sh[k]) * 2 * slot_bytes;
+      if (inside) {
+        if ((mask0 >> (pre_oi[k] - 1)) & 1ull) pre_c0[k] = *reinterpret_cast<const uint32_t*>(c + pix);
+        if ((mask1 >> (pre_oi[k] - 1)) & 1ull) pre_c1[k] = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+      }
+      pre_rec[k] = reinterpret_cast<const uint32_t*>(&objs[pre_oi[k]])[min(lane, 25)];  // motion, tex_inv, tex_base
+    }
+  }
+
+  // ---- background: frames start as its textures (masks are all 255), flow of every pixel ----
+  uint32_t px0[kPx], px1[kPx];
+  float fu[kPx], fv[kPx];
+  if (inside) {
+    if constexpr (kPow2) taps_finish(Tb, px1);
+    else {
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px1[p] = sample_bilinear(btex, gb, Rb, xx + p);
+    }
+    const uint32_t tt[4] = {bq.x, bq.y, bq.z, bq.w};
+    // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
+    const double by = (double)(y + H / 2) + (double)(-H);
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) {
+      px0[p] = tt[p] & 0x00FFFFFFu;
+      double ix = (double)(x0 + p + W / 2), iy = by;
+      const float save_x = (float)(x0 + p + W / 2), save_y = (float)(y + H / 2);
+      ix = ix + (double)(-W);
+      xform(smp.bg_motion, ix, iy);
+      ix = ix + (double)W; iy = iy + (double)H;
+      fu[p] = (float)(ix - (double)save_x);
+      fv[p] = (float)(iy - (double)save_y);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < kPx; ++p) { fu[p] = fv[p] = 0.f; px0[p] = px1[p] = 0; }
+  }
+
+  // ---- foreground objects in z-order ----
+  WarpGeom g;
+  g.tw = W; g.th = H; g.tw2 = 2 * W; g.th2 = 2 * H;
+  g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
+  g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
+  g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
+  g.pitch = fg_pitch;
+  int vi = 0;  // visit number
+#if defined(OFDG_X_ABL) && OFDG_X_ABL == 1
+  omask = 0;
+#endif
+  while (omask) {
+    const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
+    omask &= omask - 1;
+    const bool has0 = (mask0 >> (oi - 1)) & 1ull, has1 = (mask1 >> (oi - 1)) & 1ull;  // wave-uniform
+    // (opaque copies: the int -> double conversions of the pixel coordinates are redone per visit instead of being
+    //  hoisted out of the loop, where they would hold two dozen registers across every visit)
+    int xv = x0, yv = y;
+    asm volatile("" : "+v"(xv), "+v"(yv));
+    uint32_t sh, c0w = 0, c1w = 0, recw = 0;
+    if (vi < kPre) {
+      sh = vi == 0 ? pre_sh[0] : pre_sh[kPre - 1];
+      c0w = vi == 0 ? pre_c0[0] : pre_c0[kPre - 1];
+      c1w = vi == 0 ? pre_c1[0] : pre_c1[kPre - 1];
+      recw = vi == 0 ? pre_rec[0] : pre_rec[kPre - 1];
+    } else {
+      sh = shape_entry(oi);
+      if (!(sh & kShapeComposite)) {
+        const uint8_t* c = cov + (size_t)(smp.first_shape + (int)sh) * 2 * slot_bytes;
+        if (inside) {
+          if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+          if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+        }
+        recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
+      }
+    }
+    ++vi;
+    static_assert(kPre == 2 || kPre == 1, "the selects above pick between two prefetched sets");
+
+    uint32_t m0w, m1w, n0w;  // blending masks of the two frames and the thresholded frame-0 mask, byte p = pixel p
+    if (!(sh & kShapeComposite)) {
+      // the box touches the block but the outline covers none of this strip's pixels: nothing to mask, sample or blend
+      if (__ballot((c0w | c1w) != 0u) == 0ull) continue;
+#if defined(OFDG_X_ABL) && OFDG_X_ABL == 5
+      px0[0] ^= c0w & 1; continue;
+#endif
+      m0w = 0; m1w = 0; n0w = 0;
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
+        const int na0 = c0 >= 128 ? 255 : 0;
+        n0w |= (uint32_t)na0 << (8 * p);
+        m0w |= (uint32_t)(use_aa ? aa_byte(c0) : na0) << (8 * p);
+        m1w |= (uint32_t)(use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0)) << (8 * p);
+      }
+    } else {
+      // composite: sequential fp32 add / subtract over the components (DG:591-646)
+      const DevObjectHdr h = *reinterpret_cast<const DevObjectHdr*>(&objs[oi].tex_base);
+      int ua0[kPx], ua1[kPx], un1[kPx], na0[kPx];
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) { ua0[p] = ua1[p] = un1[p] = 0; na0[p] = 0; }
+      for (int k = 0; k < h.n_shapes; ++k) {
+        const uint8_t* c = cov + (size_t)(h.first_shape + k) * 2 * slot_bytes;
+        uint32_t k0w = 0, k1w = 0;
+        if (inside) {
+          // a component's coverage exists only in the 64 x 8 blocks its own box touches
+          const int by0c = ty0 + (sub >> 1) * kBandRows;
+          const DevShapeFrame F0 = frames[(h.first_shape + k) * 2], F1 = frames[(h.first_shape + k) * 2 + 1];
+          const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
+          const bool v1 = F1.x0 <= F1.x1 && F1.x0 <= tx0 + kTileW - 1 && F1.x1 >= tx0 && F1.y0 <= by0c + kBandRows - 1 && F1.y1 >= by0c;
+          if (has0 && v0) k0w = *reinterpret_cast<const uint32_t*>(c + pix);
+          if (has1 && v1) k1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+        }
+        const bool additive = (h.additive >> k) & 1u;
+#pragma unroll
+        for (int p = 0; p < kPx; ++p) {
+          const int c0 = (int)((k0w >> (8 * p)) & 255), c1 = (int)((k1w >> (8 * p)) & 255);
+          const int va0 = aa_byte(c0), va1 = aa_byte(c1);
+          const int vn0 = c0 >= 128 ? 255 : 0, vn1 = c1 >= 128 ? 255 : 0;
+          if (additive) {
+            ua0[p] = comp_add(ua0[p], va0); ua1[p] = comp_add(ua1[p], va1);
+            na0[p] = comp_add(na0[p], vn0); un1[p] = comp_add(un1[p], vn1);
+          } else {
+            ua0[p] = comp_sub(ua0[p], va0); ua1[p] = comp_sub(ua1[p], va1);
+            na0[p] = comp_sub(na0[p], vn0); un1[p] = comp_sub(un1[p], vn1);
+          }
+        }
+      }
+      m0w = 0; m1w = 0; n0w = 0;
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        m0w |= (uint32_t)(use_aa ? ua0[p] : na0[p]) << (8 * p);
+        m1w |= (uint32_t)(use_aa ? ua1[p] : un1[p]) << (8 * p);
+        n0w |= (uint32_t)na0[p] << (8 * p);
+      }
+      if (__ballot((m0w | m1w | n0w) != 0u) == 0ull) continue;
+      recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
+    }
+
+    // the object's matrices: dword i of the record sits in lane i
+    auto rec_double = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane((int)recw, 2 * i + 1), __builtin_amdgcn_readlane((int)recw, 2 * i)); };
+    // origin of the W x H centre crop: dwords 24, 25 of the record
+    const uint32_t* tex = pool + (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)recw, 25) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)recw, 24));
+    // frame 0 texture: identity warp == the crop itself (DG:339-340); issued with the frame-1 taps: one round trip
+    uint4 q0 = make_uint4(0, 0, 0, 0);
+    if (m0w) q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yv * g.pitch + xv));
+    if (__ballot(m1w != 0u)) {
+      Mat ti;
+      ti.sx = rec_double(6); ti.shy = rec_double(7); ti.shx = rec_double(8); ti.sy = rec_double(9); ti.tx = rec_double(10); ti.ty = rec_double(11);
+      const RowDDA R = make_row<kPow2>(ti, yv, W, g.nshift);
+      uint32_t t1[kPx];
+      if constexpr (kPow2) {
+#if defined(OFDG_X_ABL) && OFDG_X_ABL == 2
+        t1[0] = q0.x + R.x1; t1[1] = q0.y + R.lx; t1[2] = q0.z + R.y1; t1[3] = q0.w + R.ly;
+#else
+        const Taps4 T = taps_issue(tex, g, R, xv, m1w != 0u);
+        taps_finish(T, t1);
+#endif
+      } else {
+#pragma unroll
+        for (int p = 0; p < kPx; ++p) t1[p] = m1w ? sample_bilinear(tex, g, R, xv + p) : 0u;
+      }
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (m1w >> (8 * p)) & 255u);  // m == 0 leaves the pixel as is
+    }
+    if (m0w) {
+      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (m0w >> (8 * p)) & 255u);
+    }
+#if defined(OFDG_X_ABL) && OFDG_X_ABL == 3
+    if (false) {
+#else
+    if (__ballot(n0w != 0u)) {
+#endif
+      // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns
+      Mat mo;
+      mo.sx = rec_double(0); mo.shy = rec_double(1); mo.shx = rec_double(2); mo.sy = rec_double(3); mo.tx = rec_double(4); mo.ty = rec_double(5);
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) {
+        if (((n0w >> (8 * p)) & 255u) == 255u) {
+          double ix = (double)(xv + p), iy = (double)yv;
+          const float save_x = (float)(xv + p), save_y = (float)yv;
+          xform(mo, ix, iy);
+          fu[p] = (float)(ix - (double)save_x);
+          fv[p] = (float)(iy - (double)save_y);
+        }
+      }
+    }
+  }
+
+  if (!inside) return;
+  // u8 -> float planes (DG:1229-1245); streaming 16-byte stores, never re-read.  Every plane is a wave-uniform base
+  // (SGPR pair) + one 32-bit byte offset per lane; the offset is made opaque so that no address arithmetic is
+  // hoisted above the object loop (it would hold registers there).
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const size_t plane = (size_t)W * H;
+  uint32_t ob = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 4u;
+  asm volatile("" : "+v"(ob));
+  char* b0 = reinterpret_cast<char*>(img0 + (size_t)s * 3 * plane);
+  char* b1 = reinterpret_cast<char*>(img1 + (size_t)s * 3 * plane);
+  char* bf = reinterpret_cast<char*>(flow + (size_t)s * 2 * plane);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
+               (float)((px0[2] >> (8 * c)) & 255u), (float)((px0[3] >> (8 * c)) & 255u)};
+    f32x4 b = {(float)((px1[0] >> (8 * c)) & 255u), (float)((px1[1] >> (8 * c)) & 255u),
+               (float)((px1[2] >> (8 * c)) & 255u), (float)((px1[3] >> (8 * c)) & 255u)};
+    OFDG_STORE(a, reinterpret_cast<f32x4*>(b0 + (size_t)c * plane * 4 + ob));
+    OFDG_STORE(b, reinterpret_cast<f32x4*>(b1 + (size_t)c * plane * 4 + ob));
+  }
+  f32x4 u = {fu[0], fu[1], fu[2], fu[3]};
+  f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
+  OFDG_STORE(u, reinterpret_cast<f32x4*>(bf + ob));
+  OFDG_STORE(v, reinterpret_cast<f32x4*>(bf + plane * 4 + ob));
+}
+
+#ifndef OFDG_X_WAVES
+#define OFDG_X_ATTR
+#else
+#define OFDG_X_ATTR __attribute__((amdgpu_num_vgpr(OFDG_X_WAVES)))
+#endif
+// Leading scalar parameters are preloaded into SGPRs (no load, no wait before the first record fetch).
+__global__ __launch_bounds__(64) void compose_rigid_kernel(
+    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
+    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
+    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+  compose_rigid<false>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
+                       flow, frames, item_count);
+}
+// W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads.
+__global__ __launch_bounds__(64) OFDG_X_ATTR void compose_rigid_pow2_kernel(
+    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
+    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
+    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+  compose_rigid<true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
+                      flow, frames, item_count);
+}
+
+// --------------------------------------------------------------------------
 // Mode-9 warp fields (reference: src/caffe/WarpFields.cpp = WF).
 // A field is 4 planes of S*S floats: flow x, flow y, iflow x, iflow y.
 // --------------------------------------------------------------------------

@@ -62,12 +62,34 @@ struct DevObject {
   int32_t deform;     // mode 9: warp slot + 1, 0 = rigid
   int32_t pad[2];
 };
+static_assert(sizeof(DevObject) == 136, "record layout is read dword-wise by compose");
 
+// The sample record is self-contained for the background: compose reads it with ONE scalar load batch (the
+// background's DevObject at objects[first_object] holds the same matrices; the mode-9 kernels use that one).
 struct DevSample {
   int32_t first_object;  // background first, then foreground objects by ascending ID
   int32_t n_objects;
   int32_t first_shape;
   int32_t n_shapes;
+  Mat bg_motion;         // = objects[first_object].motion
+  Mat bg_tex_inv;        // = objects[first_object].tex_inv
+  uint64_t bg_tex_base;  // = objects[first_object].tex_base
+  int32_t bg_deform;
+  int32_t pad;
+  // foreground object k (bit k of the block masks): first outline slot relative to first_shape; bit 15 = composite.
+  // In the same record as the matrices above: by the time a wave knows its block's objects these lines are in the
+  // scalar cache, and the coverage of a simple object can be fetched without first reading the object's own record.
+  uint16_t shape_of[kMaxFgObjects];
+};
+static_assert(sizeof(DevSample) == 256, "compose reads the sample record as 128 + 128 bytes");
+constexpr uint16_t kShapeComposite = 0x8000u;
+
+// The tail of a DevObject as compose reads it ahead of a visit (one 32-byte scalar load at offset 96).
+struct DevObjectHdr {
+  uint64_t tex_base;
+  int32_t first_shape, n_shapes;
+  uint32_t additive;
+  int32_t kind, id, deform;
 };
 
 // Background texture preparation of one sample (ofdg_params.background_prep = 1):

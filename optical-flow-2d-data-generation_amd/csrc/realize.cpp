@@ -140,7 +140,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       *msg = "more than 64 foreground objects in one sample";
       return OFDG_ECAPACITY;
     }
-    DevSample smp;
+    DevSample smp = DevSample();
     smp.first_object = (int32_t)out->objects.size();
     smp.first_shape = (int32_t)out->shapes.size();
     // background (DataGenerator.cpp:1183-1205, 654-663)
@@ -174,6 +174,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       o.first_shape = 0;
       o.n_shapes = 0;
       if (mode9 && pb.do_warpfield_deformation) o.deform = serve(true);  // DataGenerator.cpp:1194-1202
+      smp.bg_motion = o.motion; smp.bg_tex_inv = o.tex_inv; smp.bg_tex_base = o.tex_base; smp.bg_deform = o.deform; smp.pad = 0;
       out->objects.push_back(o);
     }
     // foreground objects; std::map order == ascending obj_id (DataGenerator.cpp:1216-1223)
@@ -217,6 +218,10 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
         if (mode9 && p.do_warpfield_deformation) o.deform = serve(false);  // DataGenerator.cpp:1164-1168
         int rc = push_shape(cfg, p, bg_motion, t, (int)out->objects.size(), (int)out->objects.size() - smp.first_object - 1, o.deform, &out->shapes, msg);
         if (rc != OFDG_OK) return rc;
+      }
+      {
+        const int local = (int)out->objects.size() - smp.first_object - 1;  // bit of the block masks
+        smp.shape_of[local] = (uint16_t)((o.first_shape - smp.first_shape) | (o.kind == 2 ? kShapeComposite : 0));
       }
       out->objects.push_back(o);
     }

@@ -19,10 +19,10 @@ for slot in range(NS):
         for t in tasks: t.n_objects = 0
     g.upload_slot(slot, tasks, B, bps, n, st)
 i0, i1, fl = ofdg.alloc_outputs(B, H, W)
-for i in range(20): g.render_slot(i % NS, i0, i1, fl, st)
+for i in range(int(os.environ.get("WARM", "20"))): g.render_slot(i % NS, i0, i1, fl, st)
 g.synchronize(st)
 g.set_profiling(2)
-for i in range(128): g.render_slot(i % NS, i0, i1, fl, st)
+for i in range(int(os.environ.get("ITERS", "128"))): g.render_slot(i % NS, i0, i1, fl, st)
 g.synchronize(st)
 print("dbg=%s overlap=%s mode=%d geom=%.1f raster=%.1f compose=%.1f us" % (
     os.environ.get("OFDG_DBG", "0"), os.environ["OFDG_OVERLAP"], MODE,

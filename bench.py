@@ -1,28 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: training samples/s (image0 + image1 + flow) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}]
     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): FlyingChairs mode 5, 512x384, batch 32 per GPU,
-16 objects, affine-only motion, AA on, synthetic 1000 x 1024x768 texture pool.
-A "step" is one pass of the whole hot path over one batch of 32 NEW samples:
+Default workload = BASELINE.json configs[1] (--config 2): FlyingChairs mode 5, 512x384, batch 32 per GPU,
+16 objects, affine-only motion, AA on, synthetic 1000 x 1024x768 texture pool.  The other BASELINE
+configurations print the same JSON line (see CONFIGS below).  A "step" is one pass of the whole hot path
+over one batch of NEW samples:
 
-  --sampler counter (default): motion/shape sampling + realize (cs_sample_realize kernel,
-      Philox counter streams) -> geom -> raster -> compose, everything on the device; the
-      only input resident in HBM is the texture pool.  Every step renders samples never
-      rendered before (global indices step*B*world + rank*B + [0, B)).
-  --sampler resident: the reference's 45 mt19937 streams are sampled on the host before the
-      timed region; NSLOT realised batches are resident in HBM and rotated (their
-      backgrounds together exceed the 256 MiB Infinity Cache); a step is geom -> raster ->
-      compose.
+  --sampler counter (default): motion/shape sampling + realize (cs_sample_realize kernel, Philox counter
+      streams) -> geom -> raster -> compose, everything on the device; the only input resident in HBM is the
+      texture pool (mode 9: + the warp crops).  Every step renders samples never rendered before (global
+      indices step*B*world + rank*B + [0, B)).
+  --sampler resident: the reference's 45 mt19937 streams are sampled on the host before the timed region;
+      NSLOT realised batches are resident in HBM and rotated; a step is geom -> raster -> compose.
 
-The calls are made the way a prefetch ring makes them: call k renders into output buffer set k mod 4 on the
-context's next internal stream (ofdg_stream), so the kernels of neighbouring steps overlap on the device; the
-timed region ends with a device-wide synchronisation.
+The calls are made the way a prefetch ring makes them: call k renders into output buffer set k mod NBUF on the
+context's next internal stream (ofdg_stream); NBUF = 2 x the number of internal streams, so a buffer set is
+always written by the same in-order stream and the calls in flight never share an output.  The timed region
+ends with a device-wide synchronisation.
 
-Samples shard across ranks with no data-path collective ("weak" scaling): rank r renders
-block r of every B*world consecutive samples of the stream.
+Samples shard across ranks with no data-path collective ("weak" scaling): rank r renders block r of every
+B*world consecutive samples of the stream.  Start-up for N > 1: ONE native RCCL broadcast of rank 0's setup
+header + texture index table (ofdg_comm_bcast_setup, csrc/comm.cpp).
 """
 import argparse
 import importlib
@@ -34,41 +35,80 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, MODE, BATCH, NOBJ = 512, 384, 5, 32, 16
-POOL_N, POOL_W, POOL_H, POOL_SEED = 1000, 1024, 768, 2024
+# BASELINE.json configs.  pool = (n, w, h); batch = samples per GPU and step.
+CONFIGS = {
+    1: dict(mode=7, W=512, H=384, batch=1, nobj=1, pool=(1000, 1024, 768), sampler="ref",
+            name="FlyingChairs default mode (7), 512x384, batch=1, 1 object, fixed seeds 0..44 (BASELINE configs[0])"),
+    2: dict(mode=5, W=512, H=384, batch=32, nobj=16, pool=(1000, 1024, 768), sampler="counter",
+            name="FlyingChairs mode 5, 512x384, batch=32 per GPU, 16 objects, affine-only motion, AA on, "
+                 "synthetic 1000x(1024x768) texture pool (BASELINE configs[1])"),
+    3: dict(mode=9, W=512, H=384, batch=32, nobj=16, pool=(1000, 1024, 768), sampler="counter",
+            name="ThinPlate/deformation mode 9, 512x384, batch=32 per GPU, 16 objects, warp fields generated on the "
+                 "device (BASELINE configs[2])"),
+    4: dict(mode=7, W=1024, H=768, batch=8, nobj=32, pool=(1000, 2048, 1536), sampler="counter",
+            name="FlyingChairs mode 7, 1024x768, batch=8 per GPU (64 over 8 GPUs), 32 objects, mixed motion, "
+                 "synthetic 1000x(2048x1536) texture pool (BASELINE configs[3])"),
+    5: dict(mode=7, W=512, H=384, batch=32, nobj=0, pool=(10000, 1024, 1024), sampler="counter",
+            name="large-pool stress: 10000 x 1 MP textures (42 GB BGRX) resident in HBM, mode 7, 512x384, batch=32 per "
+                 "GPU (256 over 8 GPUs) (BASELINE configs[4])"),
+}
+POOL_SEED = 2024
 NSLOT = 12
-NBUF = 4    # output buffer sets the bench cycles (one per call in flight)
 SEED = 20261003
-ALG_BYTES_PER_SAMPLE = 38 * W * H       # 32 B/px written (8 fp32 planes) + 6 B/px background read
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(ofdg, gen, budget_s=15.0):
-    """The oracle (CPU restatement of the reference path, per-object full-frame work like
-    the reference) timed on this host's cores with the reference's threading: one sample
-    worker per core (first_level_threads = cores, second_level_threads = 1,
-    DataGenerator.cpp:1023-1027).  A bounded sample of the same workload."""
+def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores, on a bounded sample of the
+    same workload: 1 thread and all cores (the reference's threading: one sample worker per core,
+    first_level_threads = cores, second_level_threads = 1, DataGenerator.cpp:1023-1027), in the reference's work
+    pattern ("faithful": 4 rasterisations + full-frame warps and blits per shape, DataGenerator.cpp:337-349,
+    465-479) and in a "lean" form (one rasterisation per frame, work inside the outlines' boxes; same bytes)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as oracle
+    W, H, mode, nobj = cfg["W"], cfg["H"], cfg["mode"], cfg["nobj"]
     cores = os.cpu_count() or 1
-    n = max(cores, 8)  # one task per worker thread and round
-    tasks, bps, n_bps = ofdg.HostSampler(MODE, W, H, NOBJ).next(n, cap=n * 64)
-    sub = np.stack([gen.pool_download(i) for i in range(4)])  # tex_id % 4: same work, small host pool
-    prm = oracle.default_params(W, H, MODE, 1, 1, NOBJ)
-    t0 = time.perf_counter()
-    oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
-    first = time.perf_counter() - t0
-    done = n
-    reps = int(max(0, min((budget_s - first) / max(first, 1e-6), 64)))
-    for _ in range(reps):
-        oracle.render(prm, tasks, n, bps, n_bps, sub, n_threads=cores)
-        done += n
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d samples of this workload (mode %d, %dx%d, %d objects; 4-texture host pool subset) in %.1f s; "
-                      "oracle/ restatement with the reference's per-object full-frame work, %d worker threads" %
-                      (done, MODE, W, H, NOBJ, dt, cores)}
+    n_pool = min(host_pool, cfg["pool"][0])
+    sub = np.stack([gen.pool_download(i) for i in range(n_pool)])  # tex_id % n_pool
+    prm = oracle.default_params(W, H, mode, 1, 1, nobj)
+    crops = None
+    if mode == 9:
+        crops = np.stack([gen.warp_download(i) for i in range(min(gen.warp_count(), 8))])
+    sampler = ofdg.HostSampler(mode, W, H, nobj)
+
+    def run(n_threads, lean, budget):
+        n = max(n_threads, 2)
+        tasks, bps, n_bps = sampler.next(n, cap=n * 64)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            if lean:
+                with oracle.lean():
+                    oracle.render(prm, tasks, n, bps, n_bps, sub, warp_crops=crops, n_threads=n_threads)
+            else:
+                oracle.render(prm, tasks, n, bps, n_bps, sub, warp_crops=crops, n_threads=n_threads)
+            done += n
+            dt = time.perf_counter() - t0
+            if dt >= budget or dt * (done + n) / done > 1.5 * budget:
+                return done / dt, done, dt
+
+    all_threads = 1 if mode == 9 else cores  # (the oracle serves warp crops in order: mode 9 is sequential)
+    shares = {"faithful_all": 0.35, "lean_all": 0.25, "faithful_1": 0.25, "lean_1": 0.15}
+    res = {}
+    for key, share in shares.items():
+        lean = key.startswith("lean")
+        threads = all_threads if key.endswith("_all") else 1
+        rate, done, dt = run(threads, lean, budget_s * share)
+        res[key] = {"samples_per_s": rate, "threads": threads, "samples": done, "seconds": dt}
+    total = sum(v["seconds"] for v in res.values())
+    return {"value": res["faithful_all"]["samples_per_s"], "unit": "samples/s", "cores": res["faithful_all"]["threads"], "kind": "port",
+            "threads_all": res["faithful_all"]["samples_per_s"], "threads_1": res["faithful_1"]["samples_per_s"],
+            "lean": {"threads_all": res["lean_all"]["samples_per_s"], "threads_1": res["lean_1"]["samples_per_s"]},
+            "host_logical_cpus": cores, "detail": res,
+            "sample": "oracle/ restatement on this workload (mode %d, %dx%d, %s objects), host pool = the first %d of the %d "
+                      "textures; 'value' = the reference's work pattern (4 rasterisations + full-frame warps / blits per shape) on "
+                      "%d worker threads; lean = one rasterisation per frame, work inside the outlines' boxes; %.0f s of CPU time in all"
+                      % (mode, W, H, nobj or "16-23", n_pool, cfg["pool"][0], res["faithful_all"]["threads"], total)}
 
 
 def main():
@@ -76,9 +116,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sampler", choices=("counter", "resident"), default="counter")
+    ap.add_argument("--cpu-pool", type=int, default=128, help="textures of the pool the CPU baseline works on")
+    ap.add_argument("--sampler", choices=("counter", "resident"), default=None)
+    ap.add_argument("--background-prep", action="store_true",
+                    help="apply Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) to every background (DataGenerator.cpp:1186-1192)")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.sampler:
+        cfg["sampler"] = "counter" if args.sampler == "counter" else "resident"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -86,36 +133,64 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # one process per GPU: the device is bound before any HIP work
     ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
 
-    header = torch.tensor([MODE, W, H, NOBJ, POOL_N, POOL_W, POOL_H, POOL_SEED, SEED], dtype=torch.int64, device="cuda")
+    counter = cfg["sampler"] == "counter"
+    W, H, BATCH = cfg["W"], cfg["H"], cfg["batch"]
+    prm = ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH,
+                              rank=rank, world_size=world, device=local_rank, sampler=1 if counter else 0, seed=SEED,
+                              background_prep=1 if args.background_prep else 0)
+    startup = "single process"
+    gen = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
-        # the one collective of this path: rank 0's seed + stream/pool description, over RCCL
-        if rank != 0:
-            header.zero_()
-        dist.broadcast(header, src=0)
-    mode, w, h, nobj, pool_n, pool_w, pool_h, pool_seed, seed = [int(v) for v in header.tolist()]
-
-    counter = args.sampler == "counter"
-    prm = ofdg.default_params(width=w, height=h, mode=mode, num_objects=nobj, batch_size=BATCH,
-                              rank=rank, world_size=world, device=local_rank, sampler=1 if counter else 0, seed=seed)
-    gen = ofdg.Generator(prm)
-    gen.pool_synthetic(pool_n, pool_w, pool_h, pool_seed)
+        dist.init_process_group("nccl")  # (barriers and the max over ranks of the timing below)
+        try:
+            # the one collective of this path, native: rank 0's seed / stream / pool header + texture index table in ONE
+            # ncclBroadcast on the library's own RCCL communicator (the unique id travels through the launcher's store)
+            comm = ofdg.Comm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
+            if rank == 0:
+                gen = ofdg.Generator(prm)
+                gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+            setup, _table = comm.bcast_setup(gen)
+            if rank != 0:
+                prm = comm.params_of(setup)
+                gen = ofdg.Generator(prm)
+                gen.pool_from_setup(setup)
+            comm.close()
+            startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
+        except Exception as e:  # (a start-up problem must not cost the measurement: same header over torch.distributed)
+            header = torch.tensor([cfg["mode"], W, H, cfg["nobj"], *cfg["pool"], POOL_SEED, SEED], dtype=torch.int64, device="cuda")
+            if rank != 0:
+                header.zero_()
+            dist.broadcast(header, src=0)
+            mode, W, H, nobj, pn, pw, ph, pseed, seed = [int(v) for v in header.tolist()]
+            prm = ofdg.default_params(width=W, height=H, mode=mode, num_objects=nobj, batch_size=BATCH, rank=rank, world_size=world,
+                                      device=local_rank, sampler=1 if counter else 0, seed=seed,
+                                      background_prep=1 if args.background_prep else 0)
+            gen = ofdg.Generator(prm)
+            gen.pool_synthetic(pn, pw, ph, pseed)
+            startup = "torch.distributed broadcast (native start-up failed: %s)" % str(e)[:200]
+    else:
+        gen = ofdg.Generator(prm)
+        gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+    if cfg["mode"] == 9:
+        gen.warp_generate(2, SEED)  # seeded displacer lists: every rank generates the same fields
     stream = torch.cuda.current_stream().cuda_stream
-    # a prefetch ring of NBUF output buffer sets (data_param.prefetch): every call renders into the next set on the
-    # context's next internal stream (ofdg_stream), so the calls in flight overlap and never share an output
-    outs = [ofdg.alloc_outputs(BATCH, h, w) for _ in range(NBUF)]
+    NBUF = 2 * gen.num_chains()
+    outs = [ofdg.alloc_outputs(BATCH, H, W) for _ in range(NBUF)]
 
     host_sampler_rate = None
     if counter:
         def step(i):
             gen.forward(*outs[i % NBUF], gen.next_stream())  # samples (step*world + rank)*B + [0, B) on the device, then renders
+    elif cfg["sampler"] == "ref":
+        def step(i):  # config 1: the reference-stream sampler on the host inside the step, like load_batch
+            gen.forward(*outs[i % NBUF], gen.next_stream())
     else:
         # every rank walks the same reference stream and keeps its own block of each B*world tasks
-        sampler = ofdg.HostSampler(mode, w, h, nobj)
+        sampler = ofdg.HostSampler(cfg["mode"], W, H, cfg["nobj"])
         t_s = time.perf_counter()
         for slot in range(NSLOT):
             tasks, bps, n_bps = sampler.next(BATCH * world, cap=BATCH * world * 64)
@@ -161,40 +236,48 @@ def main():
         gen.synchronize(stream)
         parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
         gen.set_profiling(0)
+        alg_bytes_per_sample = 38 * W * H  # 32 B/px written (8 fp32 planes) + 6 B/px background read
         samples = args.steps * BATCH * world
         value = samples / dt
-        achieved = BATCH * ALG_BYTES_PER_SAMPLE / (compose_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per compose launch from the committed PMC passes (profiles/traffic.json)
+        achieved = BATCH * alg_bytes_per_sample / (compose_ms * 1e-3) / 1e9
+        kernel = ("compose_deform" if cfg["mode"] == 9 else "compose_rigid") + ("_pow2_kernel" if W & (W - 1) == 0 else "_kernel")
+        # HBM bytes per launch of that kernel from the PMC passes committed for THIS configuration (tools/profile_round.sh:
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script); null when no pass of this config is committed
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("compose_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            ent = tj.get("config%d" % args.config)
+            if ent and ent.get("kernel") == kernel and not args.background_prep:
+                traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         out = {
-            "metric": "training samples/sec (img0+img1+flow, 512x384)",
+            "metric": "training samples/sec (img0+img1+flow, %dx%d)" % (W, H),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
-            "config": {"workload": "FlyingChairs mode 5, 512x384, batch=32 per GPU, 16 objects, affine-only motion, "
-                                   "AA on, synthetic 1000x(1024x768) texture pool (BASELINE configs[1])",
-                       "batch_per_gpu": BATCH,
+            "config": {"workload": cfg["name"], "baseline_config": args.config, "batch_per_gpu": BATCH,
+                       "background_prep": bool(args.background_prep), "startup": startup, "output_buffer_sets": NBUF,
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
-                                   if counter else
+                                   if counter else "ref (host mt19937 streams) inside the timed region" if cfg["sampler"] == "ref" else
                                    "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "compose_pow2_kernel", "kernel_ms": compose_ms,
-                         "algorithmic_bytes_per_launch": BATCH * ALG_BYTES_PER_SAMPLE,
-                         # the pipeline runs three in-order chains: compose launches of neighbouring steps overlap each
-                         # other (and the preparation kernels) on the device, so a launch's duration is longer than the
-                         # step; launches in flight on average = kernel_ms / ms_per_step
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "kernel_ms": compose_ms,
+                         "algorithmic_bytes_per_launch": BATCH * alg_bytes_per_sample,
+                         # the pipeline runs independent in-order chains: compose launches of neighbouring steps overlap each
+                         # other (and the preparation kernels) on the device, so a launch's duration can exceed the step;
+                         # launches in flight on average = kernel_ms / ms_per_step
                          "launches_in_flight": compose_ms / (dt / args.steps * 1e3),
-                         "note": "per-launch duration of overlapping launches; whole pipeline: hbm_gbs_whole_step"},
+                         "whole_step_frac": value / world * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS,
+                         "note": "achieved = algorithmic bytes of one launch / its live HIP-event duration (launches overlap); "
+                                 "whole_step_frac = algorithmic bytes per second of the whole pipeline / peak"},
             "kernel_ms": parts,
-            "hbm_gbs_whole_step": value / world * ALG_BYTES_PER_SAMPLE / 1e9,
+            "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
         if host_sampler_rate is not None:
             out["host_ref_sampler_samples_per_s"] = host_sampler_rate
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ofdg, gen)
+            out["cpu_baseline"] = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

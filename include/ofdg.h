@@ -225,10 +225,17 @@ int ofdg_set_step(ofdg_ctx* ctx, long long step);
 /* The internal stream the NEXT render / forward call of this context will work on
  * (a hipStream_t; they take turns).  See ofdg_render. */
 void* ofdg_stream(ofdg_ctx* ctx);
+/* How many internal streams take turns: a caller that cycles k * ofdg_num_chains output buffer sets and passes
+ * ofdg_stream() finds every set always written by the same stream (no event needed between its writers). */
+int ofdg_num_chains(const ofdg_ctx* ctx);
 
 /* Wait for `stream` and for everything the context has in flight, and report
  * device-side error flags raised by kernels. */
 int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
+
+/* The same device-side error flags WITHOUT waiting for anything in flight: what a prefetch ring calls when it
+ * hands over a batch whose own completion event it has waited for (prefetch_full_.pop, LAY:269). */
+int ofdg_poll_errors(ofdg_ctx* ctx);
 
 /* ---- mode 9 (non-rigid deformation) warp fields: replaces WarpFields::CropGenerator
  * (WF:469-641), which DataGenerator::Start launches for MODE == 9 (DG:1016-1020). ---- */
@@ -308,6 +315,64 @@ int ofdg_layer_create(const char* layer_prototxt, ofdg_layer** out);
 int ofdg_layer_forward(ofdg_layer* layer, float** image0, float** image1, float** flow,
                        int* shape4);
 void ofdg_layer_destroy(ofdg_layer* layer);
+/* data_param.prefetch > 1: how many of the batches rendered ahead were still unfinished when the last
+ * ofdg_layer_forward returned (it waits for the oldest batch only, like prefetch_full_.pop, LAY:269). */
+int ofdg_layer_in_flight(const ofdg_layer* layer);
+
+/* ---- multi-GPU start-up (one process per GPU) -----------------------------------------------
+ * Samples shard by global index with no data-path collective; what the ranks must agree on is the stream and
+ * the pool.  ONE RCCL broadcast (ncclBroadcast over xGMI) carries rank 0's setup header + texture index table.
+ * The reference has nothing to replace here: Caffe's multi-GPU solvers each build their own layer from the same
+ * prototxt and the same 45 seeds (data_generation_layer.hpp:54, DG:1360) and so render identical samples. */
+#define OFDG_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+#define OFDG_POOL_SYNTHETIC 0    /* every rank generates the pool itself from pool_seed */
+#define OFDG_POOL_UNIFORM   1    /* images of one size (pool_w x pool_h), contents replicated with ofdg_comm_bcast_pool */
+#define OFDG_POOL_MIXED     2    /* images of different sizes (ofdg_pool_alloc_mixed), contents replicated likewise */
+typedef struct ofdg_setup {
+  int32_t seed, mode, width, height, num_objects, use_antialiasing, batch_size, sampler, background_prep;
+  int32_t n_tex;          /* images in the texture pool */
+  int32_t pool_kind;      /* OFDG_POOL_* */
+  int32_t pool_w, pool_h; /* image size (0 x 0 for a mixed pool) */
+  uint32_t pool_seed;     /* synthetic pools */
+  int32_t n_table;        /* valid entries of the index table that travels with the header */
+  int32_t reserved;
+} ofdg_setup;
+/* One texture of the pool as the kernels address it: `offset` texels into the pool the foreground path reads,
+ * rows `pitch` texels apart; w x h = size of the source image. */
+typedef struct ofdg_tex_entry {
+  uint64_t offset;
+  uint32_t w, h, pitch, reserved;
+} ofdg_tex_entry;
+typedef struct ofdg_comm ofdg_comm;
+/* rank 0: ncclGetUniqueId into id[OFDG_UNIQUE_ID_BYTES]; hand it to the other processes through the launcher's
+ * rendezvous (file, environment, key-value store). */
+int ofdg_comm_unique_id(void* id);
+/* hipSetDevice(device), then ncclCommInitRank.  Call it before any other HIP work of the process. */
+int ofdg_comm_init(const void* id, int rank, int world_size, int device, ofdg_comm** out);
+/* Use a communicator the caller already owns (an ncclComm_t); it is not destroyed by ofdg_comm_destroy. */
+int ofdg_comm_adopt(void* nccl_comm, int rank, int world_size, int device, ofdg_comm** out);
+void ofdg_comm_destroy(ofdg_comm* comm);
+int ofdg_comm_rank(const ofdg_comm* comm);
+int ofdg_comm_world_size(const ofdg_comm* comm);
+const char* ofdg_comm_last_error(const ofdg_comm* comm);
+/* THE start-up collective: root's *setup and table[0 .. setup->n_table) reach every rank in one ncclBroadcast. */
+int ofdg_comm_bcast_setup(ofdg_comm* comm, int root, ofdg_setup* setup, ofdg_tex_entry* table, int table_cap);
+/* Replicate the root's resident pool into the (identically allocated) pools of the other ranks: ncclBroadcast
+ * between the HBM pools, so that only the root reads the texture collection from disk (DG:117-149). */
+int ofdg_comm_bcast_pool(ofdg_comm* comm, int root, ofdg_ctx* ctx);
+/* The header / index table of a context's stream and pool (what the root broadcasts), and the parameters a
+ * receiving rank creates its context with (rank, world_size and device come from the communicator). */
+int ofdg_setup_of(const ofdg_ctx* ctx, ofdg_setup* setup, ofdg_tex_entry* table, int table_cap);
+int ofdg_setup_params(const ofdg_setup* setup, const ofdg_comm* comm, ofdg_params* params);
+/* Allocate (synthetic: also fill) this rank's pool as the setup describes it. */
+int ofdg_setup_alloc_pool(ofdg_ctx* ctx, const ofdg_setup* setup);
+/* The derived textures of a mixed pool as raw device memory: [n][H][W] foreground and [n][2H][2W] background. */
+int ofdg_pool_device_mixed(ofdg_ctx* ctx, void** fg, unsigned long long* fg_bytes, void** bg,
+                           unsigned long long* bg_bytes);
+/* DataGenerationLayer on a communicator: every rank passes the same prototxt; rank 0's options and texture
+ * collection win (one broadcast), rank / world_size / device come from the communicator, and Forward yields
+ * this rank's shard of every global batch. */
+int ofdg_layer_create_dist(const char* layer_prototxt, ofdg_comm* comm, ofdg_layer** out);
 
 #ifdef __cplusplus
 }

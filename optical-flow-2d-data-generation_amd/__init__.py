@@ -58,6 +58,22 @@ class Params(C.Structure):
     ]
 
 
+class Setup(C.Structure):
+    """ofdg_setup: what rank 0 broadcasts at start-up (stream + pool description)."""
+    _fields_ = [(k, C.c_int32) for k in ("seed", "mode", "width", "height", "num_objects", "use_antialiasing", "batch_size",
+                                         "sampler", "background_prep", "n_tex", "pool_kind", "pool_w", "pool_h")] + \
+               [("pool_seed", C.c_uint32), ("n_table", C.c_int32), ("reserved", C.c_int32)]
+
+
+class TexEntry(C.Structure):
+    """ofdg_tex_entry: one texture of the index table."""
+    _fields_ = [("offset", C.c_uint64), ("w", C.c_uint32), ("h", C.c_uint32), ("pitch", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+UNIQUE_ID_BYTES = 128
+POOL_SYNTHETIC, POOL_UNIFORM, POOL_MIXED = 0, 1, 2
+
+
 class OfdgError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("ofdg error %d: %s" % (code, msg))
@@ -76,6 +92,10 @@ EXPORTS = [
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
+    "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_num_chains",
+    "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
+    "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_pool", "ofdg_setup_of", "ofdg_setup_params",
+    "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_layer_create_dist",
 ]
 
 
@@ -151,6 +171,25 @@ def lib():
         L.ofdg_layer_forward.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32 * 4)]
         L.ofdg_layer_destroy.argtypes = [vp]
         L.ofdg_layer_destroy.restype = None
+        L.ofdg_layer_in_flight.argtypes = [vp]
+        L.ofdg_poll_errors.argtypes = [vp]
+        L.ofdg_num_chains.argtypes = [vp]
+        L.ofdg_comm_unique_id.argtypes = [vp]
+        L.ofdg_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+        L.ofdg_comm_adopt.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+        L.ofdg_comm_destroy.argtypes = [vp]
+        L.ofdg_comm_destroy.restype = None
+        L.ofdg_comm_rank.argtypes = [vp]
+        L.ofdg_comm_world_size.argtypes = [vp]
+        L.ofdg_comm_last_error.argtypes = [vp]
+        L.ofdg_comm_last_error.restype = C.c_char_p
+        L.ofdg_comm_bcast_setup.argtypes = [vp, i32, C.POINTER(Setup), vp, i32]
+        L.ofdg_comm_bcast_pool.argtypes = [vp, i32, vp]
+        L.ofdg_setup_of.argtypes = [vp, C.POINTER(Setup), vp, i32]
+        L.ofdg_setup_params.argtypes = [C.POINTER(Setup), vp, C.POINTER(Params)]
+        L.ofdg_setup_alloc_pool.argtypes = [vp, C.POINTER(Setup)]
+        L.ofdg_pool_device_mixed.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(C.c_ulonglong)]
+        L.ofdg_layer_create_dist.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
         _lib = L
     return _lib
 
@@ -195,6 +234,10 @@ class Generator:
 
     def pool_alloc(self, n, w, h):
         self._check(lib().ofdg_pool_alloc(self.h, n, w, h))
+
+    def pool_from_setup(self, setup):
+        """Allocate (synthetic: also fill) the pool a broadcast Setup describes (ofdg_setup_alloc_pool)."""
+        self._check(lib().ofdg_setup_alloc_pool(self.h, C.byref(setup)))
 
     def pool_upload(self, index, bgr_planar):
         import numpy as np
@@ -333,6 +376,9 @@ class Generator:
     def step(self, k):
         self._check(lib().ofdg_set_step(self.h, int(k)))
 
+    def num_chains(self):
+        return lib().ofdg_num_chains(self.h)
+
     def next_stream(self):
         """The internal hipStream_t (int) the next render / forward call works on; pass it as that call's
         `stream` to be ordered on it directly (consecutive calls then overlap, see include/ofdg.h)."""
@@ -408,6 +454,75 @@ class Generator:
         ms = C.c_float()
         self._check(lib().ofdg_kernel_ms(self.h, name.encode(), C.byref(ms)))
         return ms.value
+
+
+class Comm:
+    """One process per GPU on an RCCL communicator (ofdg_comm): the native multi-GPU start-up.
+
+    rank 0 draws the ncclUniqueId (Comm.unique_id()) and hands it to the other processes through whatever
+    rendezvous the launcher offers (`exchange`: a callable bytes-or-None -> bytes, e.g. a torch.distributed store);
+    Comm(id, rank, world, device) binds the device and joins.  bcast_setup is THE start-up collective."""
+
+    TABLE_CAP = 16384
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib().ofdg_comm_unique_id(buf)
+        if rc != OK:
+            raise OfdgError(rc, lib().ofdg_comm_last_error(None).decode())
+        return buf.raw
+
+    def __init__(self, uid, rank, world_size, device):
+        h = C.c_void_p()
+        rc = lib().ofdg_comm_init(C.c_char_p(uid), rank, world_size, device, C.byref(h))
+        if rc != OK:
+            raise OfdgError(rc, lib().ofdg_comm_last_error(None).decode())
+        self.h, self.rank, self.world_size, self.device = h, rank, world_size, device
+
+    @classmethod
+    def from_store(cls, store, rank, world_size, device, key="ofdg_unique_id"):
+        """Join through a key-value store (torch.distributed's TCPStore / FileStore ...): rank 0 sets the id."""
+        if rank == 0:
+            uid = cls.unique_id()
+            store.set(key, uid)
+        else:
+            uid = bytes(store.get(key))
+        return cls(uid, rank, world_size, device)
+
+    def _check(self, rc):
+        if rc != OK:
+            raise OfdgError(rc, lib().ofdg_comm_last_error(self.h).decode())
+
+    def bcast_setup(self, gen=None, root=0):
+        """Root passes its Generator (stream + pool description are read off it); returns (Setup, table)."""
+        su = Setup()
+        table = (TexEntry * self.TABLE_CAP)()
+        if self.rank == root:
+            rc = lib().ofdg_setup_of(gen.h, C.byref(su), table, self.TABLE_CAP)
+            if rc != OK:
+                raise OfdgError(rc, "ofdg_setup_of")
+        self._check(lib().ofdg_comm_bcast_setup(self.h, root, C.byref(su), table, self.TABLE_CAP))
+        return su, table
+
+    def params_of(self, setup):
+        p = Params()
+        lib().ofdg_setup_params(C.byref(setup), self.h, C.byref(p))
+        return p
+
+    def bcast_pool(self, gen, root=0):
+        self._check(lib().ofdg_comm_bcast_pool(self.h, root, gen.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ofdg_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _dptr(x):
@@ -494,9 +609,9 @@ class DataGenerationLayer:
     Caffe layer): constructed from prototxt text, Forward() returns the three top blobs
     as torch tensors that alias the layer's device memory."""
 
-    def __init__(self, prototxt):
+    def __init__(self, prototxt, comm=None):
         h = C.c_void_p()
-        rc = lib().ofdg_layer_create(prototxt.encode(), C.byref(h))
+        rc = lib().ofdg_layer_create_dist(prototxt.encode(), comm.h if comm is not None else None, C.byref(h))
         if rc != OK:
             raise OfdgError(rc, lib().ofdg_host_last_error().decode())
         self.h = h
@@ -520,6 +635,10 @@ class DataGenerationLayer:
             t.copy_(src)
             outs.append(t)
         return tuple(outs)
+
+    def in_flight(self):
+        """Batches rendered ahead that were still unfinished when the last Forward returned (prefetch > 1)."""
+        return lib().ofdg_layer_in_flight(self.h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -252,18 +252,56 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
 // ---------------------------------------------------------------------------
 // DataGenerationLayer
 // ---------------------------------------------------------------------------
-DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt) : cfg_(parse_layer_prototxt(layer_prototxt)) {
+DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg_comm* comm) : cfg_(parse_layer_prototxt(layer_prototxt)) {
   if (!cfg_.type.empty() && cfg_.type != "DataGeneration") throw std::runtime_error("layer type is not \"DataGeneration\"");
-  int rc = ofdg_create(&cfg_.params, &ctx_);
-  if (rc == OFDG_EBADMODE) throw std::runtime_error("BAD MODE");  // DataGenerator.cpp:2004
-  if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_last_error(nullptr));
+  constexpr int kTableCap = 16384;
+  std::vector<ofdg_tex_entry> table;
+  ofdg_setup su;
+  std::memset(&su, 0, sizeof(su));
+  const int rank = comm ? ofdg_comm_rank(comm) : 0;
+  auto create = [&]() {
+    int rc = ofdg_create(&cfg_.params, &ctx_);
+    if (rc == OFDG_EBADMODE) throw std::runtime_error("BAD MODE");  // DataGenerator.cpp:2004
+    if (rc != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_last_error(nullptr));
+  };
+  auto bcast = [&]() {  // the one start-up collective: rank 0's stream + pool description
+    table.resize(kTableCap);
+    if (ofdg_comm_bcast_setup(comm, 0, &su, table.data(), kTableCap) != OFDG_OK)
+      throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_comm_last_error(comm));
+  };
   try {
-    load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+    if (comm) {
+      ofdg_params mine;
+      ofdg_setup_params(&su, comm, &mine);  // (rank, world_size, device of the communicator)
+      cfg_.params.rank = mine.rank; cfg_.params.world_size = mine.world_size; cfg_.params.device = mine.device;
+    }
+    if (!comm || rank == 0) {
+      create();
+      load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+      if (comm) {
+        table.resize(kTableCap);
+        ofdg_setup_of(ctx_, &su, table.data(), kTableCap);
+        bcast();
+      }
+    } else {
+      bcast();
+      ofdg_params p;
+      ofdg_setup_params(&su, comm, &p);
+      p.prefetch = cfg_.params.prefetch;
+      p.first_level_threads = cfg_.params.first_level_threads; p.second_level_threads = cfg_.params.second_level_threads;
+      cfg_.params = p;
+      create();
+      if (ofdg_setup_alloc_pool(ctx_, &su) != OFDG_OK)
+        throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx_));
+    }
+    // a texture collection read from disk lives on rank 0 only until here: replicate it over xGMI
+    if (comm && su.pool_kind != OFDG_POOL_SYNTHETIC && ofdg_comm_bcast_pool(comm, 0, ctx_) != OFDG_OK)
+      throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_comm_last_error(comm));
     // DataGenerator::Start launches the CropGenerator for MODE == 9 (DataGenerator.cpp:1016-1020)
     if (cfg_.params.mode == 9 && ofdg_warp_generate(ctx_, 2, (uint32_t)cfg_.params.seed) != OFDG_OK)
       throw std::runtime_error(std::string("warp field generation: ") + ofdg_last_error(ctx_));
   } catch (...) {
-    ofdg_destroy(ctx_);
+    if (ctx_) ofdg_destroy(ctx_);
     ctx_ = nullptr;
     throw;
   }
@@ -272,6 +310,7 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt) : cf
 DataGenerationLayer::~DataGenerationLayer() {
   if (ctx_) (void)ofdg_synchronize(ctx_, nullptr);
   for (float* p : ring_) if (p) (void)hipFree(p);
+  for (void* e : ring_done_) if (e) (void)hipEventDestroy((hipEvent_t)e);
   ofdg_destroy(ctx_);
 }
 
@@ -279,8 +318,11 @@ DataGenerationLayer::~DataGenerationLayer() {
 void DataGenerationLayer::enqueue_next() {
   const int P = (int)ring_.size() / 3;
   float** set = &ring_[(size_t)(produced_ % P) * 3];
-  if (ofdg_forward(ctx_, set[0], set[1], set[2], ofdg_stream(ctx_)) != OFDG_OK)
+  void* chain = ofdg_stream(ctx_);  // the whole batch runs in order on this internal stream
+  if (ofdg_forward(ctx_, set[0], set[1], set[2], chain) != OFDG_OK)
     throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+  if (hipEventRecord((hipEvent_t)ring_done_[(size_t)(produced_ % P)], (hipStream_t)chain) != hipSuccess)
+    throw std::runtime_error("DataGenerationLayer::Forward: hipEventRecord failed");
   ++produced_;
 }
 
@@ -295,6 +337,10 @@ void DataGenerationLayer::LayerSetUp(const std::vector<Blob*>& bottom, const std
     for (int k = 0; k < P * 3; ++k)
       if (hipMalloc((void**)&ring_[k], (size_t)N * (k % 3 == 2 ? 2 : 3) * H * W * sizeof(float)) != hipSuccess)
         throw std::runtime_error("DataGenerationLayer: hipMalloc of the prefetch buffers failed");
+    ring_done_.assign((size_t)P, nullptr);
+    for (int k = 0; k < P; ++k)
+      if (hipEventCreateWithFlags((hipEvent_t*)&ring_done_[k], hipEventDisableTiming) != hipSuccess)
+        throw std::runtime_error("DataGenerationLayer: hipEventCreate failed");
     while (produced_ < P - 1) enqueue_next();
   }
   if (!ring_.empty())
@@ -316,10 +362,16 @@ void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const st
     // caller's own work takes longer than a render - becomes the tops; its successor starts rendering at once
     const int P = (int)ring_.size() / 3;
     if (produced_ == consumed_) enqueue_next();
-    if (ofdg_synchronize(ctx_, nullptr) != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+    // wait for THIS set's event only: the batches behind it keep rendering
+    if (hipEventSynchronize((hipEvent_t)ring_done_[(size_t)(consumed_ % P)]) != hipSuccess)
+      throw std::runtime_error("DataGenerationLayer::Forward: hipEventSynchronize failed");
+    if (ofdg_poll_errors(ctx_) != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
     float** set = &ring_[(size_t)(consumed_ % P) * 3];
     for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
     ++consumed_;
+    in_flight_ = 0;
+    for (long long b = consumed_; b < produced_; ++b)
+      if (hipEventQuery((hipEvent_t)ring_done_[(size_t)(b % P)]) == hipErrorNotReady) ++in_flight_;
     while (produced_ < consumed_ + P - 1) enqueue_next();
     return;
   }
@@ -412,12 +464,13 @@ int ofdg_parse_prototxt(const char* text, ofdg_params* out, char* texture_dbases
   }
 }
 
-int ofdg_layer_create(const char* prototxt, ofdg_layer** out) {
+int ofdg_layer_create(const char* prototxt, ofdg_layer** out) { return ofdg_layer_create_dist(prototxt, nullptr, out); }
+int ofdg_layer_create_dist(const char* prototxt, ofdg_comm* comm, ofdg_layer** out) {
   if (!prototxt || !out) return OFDG_EINVAL;
   *out = nullptr;
   std::unique_ptr<ofdg_layer> L(new ofdg_layer());
   try {
-    L->layer.reset(new DataGenerationLayer(prototxt));
+    L->layer.reset(new DataGenerationLayer(prototxt, comm));
     std::vector<Blob*> top = {&L->top[0], &L->top[1], &L->top[2]};
     L->layer->LayerSetUp({}, top);
   } catch (const std::exception& e) {
@@ -430,6 +483,7 @@ int ofdg_layer_create(const char* prototxt, ofdg_layer** out) {
   return OFDG_OK;
 }
 void ofdg_layer_destroy(ofdg_layer* L) { delete L; }
+int ofdg_layer_in_flight(const ofdg_layer* L) { return L ? L->layer->in_flight_after_last_forward() : OFDG_EINVAL; }
 // Forward(): fills the three top blobs and returns their device pointers.
 int ofdg_layer_forward(ofdg_layer* L, float** image0, float** image1, float** flow, int* shape4) {
   if (!L) return OFDG_EINVAL;

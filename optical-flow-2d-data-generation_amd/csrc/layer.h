@@ -52,7 +52,9 @@ LayerConfig parse_layer_prototxt(const std::string& text);
 
 class DataGenerationLayer {
  public:
-  explicit DataGenerationLayer(const std::string& layer_prototxt);
+  // comm != nullptr: one layer per GPU/process on an RCCL communicator - rank 0's options and texture collection
+  // are broadcast (ofdg_comm_bcast_setup), every rank renders its own shard of each global batch.
+  explicit DataGenerationLayer(const std::string& layer_prototxt, ofdg_comm* comm = nullptr);
   ~DataGenerationLayer();
 
   void LayerSetUp(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
@@ -69,6 +71,8 @@ class DataGenerationLayer {
   // cycled, P - 1 batches are rendered ahead on the context's internal streams (from
   // LayerSetUp on) while the caller works on the current one, and Forward points the top
   // blobs at the finished set instead of copying it (valid until the next Forward).
+  // Forward waits for the OLDEST set's own completion event only (prefetch_full_.pop,
+  // data_generation_layer.cpp:269): the younger batches stay in flight behind it.
   void Forward_cpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Forward_gpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Backward_cpu(const std::vector<Blob*>&, const std::vector<bool>&, const std::vector<Blob*>&) {}
@@ -82,6 +86,12 @@ class DataGenerationLayer {
   LayerConfig cfg_;
   ofdg_ctx* ctx_ = nullptr;
   std::vector<float*> ring_;       // [prefetch][3] device buffers (prefetch > 1)
+  std::vector<void*> ring_done_;   // [prefetch] hipEvent_t: the set's batch is complete
+ public:
+  // batches rendered ahead that had not finished when the last Forward returned (diagnostics / tests)
+  int in_flight_after_last_forward() const { return in_flight_; }
+ private:
+  int in_flight_ = 0;
   long long produced_ = 0, consumed_ = 0;
 };
 

@@ -54,6 +54,9 @@ struct ofdg_ctx {
   TexSource fg_src{}, bg_src{};
   bool pool_final = false;       // derived pools match the current pool contents
   bool pool_mixed = false;       // ofdg_pool_alloc_mixed: only the derived pools exist (images of different sizes)
+  std::vector<std::pair<int, int>> mixed_sizes;  // source image sizes of a mixed pool (index table)
+  int pool_kind = OFDG_POOL_UNIFORM;
+  uint32_t pool_seed = 0;
   // sampler
   std::unique_ptr<RefSampler> sampler;
   long long step = 0;
@@ -142,6 +145,8 @@ struct ofdg_ctx {
   bool overlap = true;
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
+  uint32_t* h_err = nullptr;        // pinned copy for ofdg_poll_errors, on its own stream
+  hipStream_t err_stream = nullptr;
   // profiling: ring of event sets, 6 events per launch: start/stop of geom, raster and compose,
   // attached to the kernels' own dispatch packets
   int profiling = 0;  // 0 off, 1 compose kernel only, 2 all three kernels
@@ -317,6 +322,8 @@ void ofdg_destroy(ofdg_ctx* c) {
   c->d_cs_bps.release(); c->d_cs_nobj.release();
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
+  if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->err_stream) (void)hipStreamDestroy(c->err_stream);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
 }
@@ -341,6 +348,7 @@ int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
   c->pool_n = n; c->pool_w = w; c->pool_h = h;
   c->pool_final = false;
   c->pool_mixed = false;
+  c->pool_kind = OFDG_POOL_UNIFORM;
   return OFDG_OK;
 }
 
@@ -366,6 +374,8 @@ int ofdg_pool_alloc_mixed(ofdg_ctx* c, int n) {
   c->bg_src = TexSource{(uint64_t)4 * W * H, 0, 2 * W, 0};
   c->pool_mixed = true;
   c->pool_final = true;
+  c->pool_kind = OFDG_POOL_MIXED;
+  c->mixed_sizes.assign((size_t)n, std::make_pair(0, 0));
   return OFDG_OK;
 }
 
@@ -391,6 +401,7 @@ int ofdg_pool_upload_mixed(ofdg_ctx* c, int index, const uint8_t* bgr_planar, in
   if (rc == OFDG_OK) rc = texture_of_image(c, img, w, h, 2 * W, 2 * H, c->pool_bg + (size_t)index * 4 * W * H);
   HIP_OK(c, hipDeviceSynchronize());
   (void)hipFree(tmp); (void)hipFree(img);
+  if (rc == OFDG_OK) c->mixed_sizes[(size_t)index] = std::make_pair(w, h);
   return rc;
 }
 
@@ -401,6 +412,8 @@ int ofdg_pool_synthetic(ofdg_ctx* c, int n, int w, int h, uint32_t seed) {
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipDeviceSynchronize());
   c->pool_final = false;
+  c->pool_kind = OFDG_POOL_SYNTHETIC;
+  c->pool_seed = seed;
   return OFDG_OK;
 }
 
@@ -454,6 +467,49 @@ int ofdg_pool_device(ofdg_ctx* c, void** ptr, unsigned long long* bytes, int mar
   *bytes = (unsigned long long)c->pool_n * c->pool_w * c->pool_h * sizeof(uint32_t);
   if (mark_written) c->pool_final = false;
   return OFDG_OK;
+}
+
+int ofdg_pool_device_mixed(ofdg_ctx* c, void** fg, unsigned long long* fg_bytes, void** bg, unsigned long long* bg_bytes) {
+  if (!c || !fg || !fg_bytes || !bg || !bg_bytes) return OFDG_EINVAL;
+  if (!c->pool_mixed) { c->err = "pool_device_mixed: needs a mixed pool (ofdg_pool_alloc_mixed)"; return OFDG_ETEXTURES; }
+  HIP_OK(c, hipDeviceSynchronize());
+  const unsigned long long px = (unsigned long long)c->prm.width * c->prm.height;
+  *fg = (void*)c->pool_fg; *fg_bytes = (unsigned long long)c->pool_n * px * sizeof(uint32_t);
+  *bg = (void*)c->pool_bg; *bg_bytes = (unsigned long long)c->pool_n * 4 * px * sizeof(uint32_t);
+  return OFDG_OK;
+}
+
+// ---- multi-GPU start-up: what the root broadcasts (csrc/comm.cpp) ------------------------------------
+int ofdg_setup_of(const ofdg_ctx* c, ofdg_setup* su, ofdg_tex_entry* table, int table_cap) {
+  if (!c || !su || table_cap < 0 || (table_cap > 0 && !table)) return OFDG_EINVAL;
+  std::memset(su, 0, sizeof(*su));
+  const ofdg_params& p = c->prm;
+  su->seed = p.seed; su->mode = p.mode; su->width = p.width; su->height = p.height; su->num_objects = p.num_objects;
+  su->use_antialiasing = p.use_antialiasing; su->batch_size = p.batch_size; su->sampler = p.sampler;
+  su->background_prep = p.background_prep;
+  su->n_tex = c->pool_n; su->pool_kind = c->pool_kind; su->pool_w = c->pool_w; su->pool_h = c->pool_h; su->pool_seed = c->pool_seed;
+  su->n_table = std::min(c->pool_n, table_cap);
+  const uint64_t W = (uint64_t)p.width, H = (uint64_t)p.height;
+  for (int i = 0; i < su->n_table; ++i) {
+    ofdg_tex_entry& e = table[i];
+    std::memset(&e, 0, sizeof(e));
+    if (c->pool_mixed) {  // the path reads the derived [n][H][W] foreground textures
+      e.offset = (uint64_t)i * W * H; e.pitch = (uint32_t)W;
+      e.w = (uint32_t)c->mixed_sizes[(size_t)i].first; e.h = (uint32_t)c->mixed_sizes[(size_t)i].second;
+    } else {
+      e.offset = (uint64_t)i * (uint64_t)c->pool_w * (uint64_t)c->pool_h; e.pitch = (uint32_t)c->pool_w;
+      e.w = (uint32_t)c->pool_w; e.h = (uint32_t)c->pool_h;
+    }
+  }
+  return OFDG_OK;
+}
+
+int ofdg_setup_alloc_pool(ofdg_ctx* c, const ofdg_setup* su) {
+  if (!c || !su) return OFDG_EINVAL;
+  if (su->width != c->prm.width || su->height != c->prm.height) { c->err = "setup_alloc_pool: the context was not created from this setup"; return OFDG_EINVAL; }
+  if (su->pool_kind == OFDG_POOL_SYNTHETIC) return ofdg_pool_synthetic(c, su->n_tex, su->pool_w, su->pool_h, su->pool_seed);
+  if (su->pool_kind == OFDG_POOL_MIXED) return ofdg_pool_alloc_mixed(c, su->n_tex);
+  return ofdg_pool_alloc(c, su->n_tex, su->pool_w, su->pool_h);
 }
 
 // ---- sampler ---------------------------------------------------------------------------
@@ -1011,6 +1067,7 @@ int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, floa
 // A caller that passes it as that call's `stream` gets the outputs ordered on it and no cross-stream wait
 // at all; with any other stream the compose kernel runs on that stream after one event (standard stream
 // semantics: the compose kernels of consecutive calls then run one after the other).
+int ofdg_num_chains(const ofdg_ctx* c) { return c ? c->n_chains : OFDG_EINVAL; }
 void* ofdg_stream(ofdg_ctx* c) {
   if (!c) return nullptr;
   return (void*)c->chains[c->next_chain % (unsigned)c->n_chains].stream;
@@ -1111,6 +1168,27 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
   if (e) {
     HIP_OK(c, hipMemset(c->d_err, 0, sizeof(uint32_t)));
+    c->err = "device capacity exceeded:";
+    if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
+    if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
+    if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
+    return OFDG_ECAPACITY;
+  }
+  return OFDG_OK;
+}
+
+// The device-side error flags without waiting for anything in flight (a prefetch ring checks them when it hands
+// a finished batch over; flags of younger batches are reported at their own hand-over at the latest).
+int ofdg_poll_errors(ofdg_ctx* c) {
+  if (!c) return OFDG_EINVAL;
+  if (!c->h_err) HIP_OK(c, hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocDefault));
+  if (!c->err_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->err_stream, hipStreamNonBlocking));
+  HIP_OK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->err_stream));
+  HIP_OK(c, hipStreamSynchronize(c->err_stream));
+  const uint32_t e = *c->h_err;
+  if (e) {
+    HIP_OK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->err_stream));
+    HIP_OK(c, hipStreamSynchronize(c->err_stream));
     c->err = "device capacity exceeded:";
     if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
     if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";

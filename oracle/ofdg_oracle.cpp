@@ -222,12 +222,18 @@ struct Object {
   bool has_warp = false;
   const WarpCrop* warp = nullptr;
   std::unique_ptr<WarpCrop> own_warp;  // background's upscaled copy
+  // lean cost model only: pixels outside this box are zero in both masks of frame f (inclusive; empty: x0 > x1)
+  int bb[2][4] = {{0, 0, -1, -1}, {0, 0, -1, -1}};
 };
 
 struct Ctx {
   int W, H, mode;
   bool use_AA;
-  bool faithful;  // 4 rasterisations per shape like the reference (cost model)
+  // true: the reference's work pattern - 4 rasterisations and 2 full-frame texture warps per shape, full-frame
+  // composites and blits for every object, visible or not (DG:337-349, 465-479, 762-799).  false ("lean", CPU
+  // baseline only, same output bit for bit): one rasterisation per frame, work restricted to the outline's box,
+  // identity warps are copies, objects entirely off-screen are skipped.
+  bool faithful;
   bool background_prep = false;  // Texture::getRandomizedCrop with the sampled rotation / zoom / shift (DG:1186-1192)
 };
 
@@ -277,12 +283,49 @@ void apply_warp(const std::vector<uint8_t>& in, int W, int H, int channels, cons
       }
 }
 
+// lean: ONE rasterisation gives both masks of a frame (gamma_threshold(0.5) of the same raw coverage, AGG B.4),
+// computed inside the outline's pixel box only
+void draw_lean(const Ctx& c, const std::vector<PointD>& poly, Object& o, int f, bool* ok) {
+  const size_t n = (size_t)c.W * c.H;
+  o.mask_AA[f].assign(n, 0);
+  o.mask_noAA[f].assign(n, 0);
+  double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300;
+  for (const PointD& p : poly) { mnx = std::min(mnx, p.x); mxx = std::max(mxx, p.x); mny = std::min(mny, p.y); mxy = std::max(mxy, p.y); }
+  int x0 = (int)std::floor(std::max(mnx, -4.0)) - 2, y0 = (int)std::floor(std::max(mny, -4.0)) - 2;
+  int x1 = (int)std::floor(std::min(mxx, c.W + 4.0)) + 2, y1 = (int)std::floor(std::min(mxy, c.H + 4.0)) + 2;
+  x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, c.W - 1); y1 = std::min(y1, c.H - 1);
+  if (poly.empty() || x0 > x1 || y0 > y1) { o.bb[f][0] = 0; o.bb[f][1] = 0; o.bb[f][2] = -1; o.bb[f][3] = -1; return; }
+  std::vector<uint8_t> cov(n);
+  if (!rasterize_polygon(poly, c.W, c.H, cov.data(), false)) *ok = false;
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      const uint8_t cv = cov[(size_t)y * c.W + x];
+      o.mask_AA[f][(size_t)y * c.W + x] = gray8_solid_on_clear(cv);
+      o.mask_noAA[f][(size_t)y * c.W + x] = cv >= 128 ? 255 : 0;
+    }
+  o.bb[f][0] = x0; o.bb[f][1] = y0; o.bb[f][2] = x1; o.bb[f][3] = y1;
+}
+void full_box(const Ctx& c, Object& o, int f) { o.bb[f][0] = 0; o.bb[f][1] = 0; o.bb[f][2] = c.W - 1; o.bb[f][3] = c.H - 1; }
+
 // renderMasks (DG:465-479 ellipse, DG:520-534 polygon, DG:370-386 warp part).
 void render_shape_masks(const Ctx& c, Object& o, const ShapeGeom& g, bool* ok) {
   Affine save = o.intrinsic;
   save *= o.motion;
   std::vector<PointD> p0 = outline(g, o.intrinsic);
   std::vector<PointD> p1 = outline(g, save);
+  if (!c.faithful) {
+    draw_lean(c, p0, o, 0, ok);
+    draw_lean(c, p1, o, 1, ok);
+    if (o.has_warp) {  // (the warped mask can be non-zero anywhere)
+      std::vector<uint8_t> t;
+      apply_warp(o.mask_noAA[1], c.W, c.H, 1, *o.warp, true, t);
+      o.mask_noAA[1].swap(t);
+      apply_warp(o.mask_AA[1], c.W, c.H, 1, *o.warp, true, t);
+      o.mask_AA[1].swap(t);
+      full_box(c, o, 1);
+    }
+    return;
+  }
   draw(c, p0, true, o.mask_AA[0], ok);
   draw(c, p0, false, o.mask_noAA[0], ok);
   draw(c, p1, true, o.mask_AA[1], ok);
@@ -300,6 +343,18 @@ void render_shape_masks(const Ctx& c, Object& o, const ShapeGeom& g, bool* ok) {
 void render_textures(const Ctx& c, Object& o) {
   o.tex[1].resize(o.tex[0].size());
   o.tex[2].resize(o.tex[0].size());
+  if (!c.faithful) {
+    if (o.bb[0][0] <= o.bb[0][2]) o.tex[1] = o.tex[0];  // identity warp == copy (all fractional weights are 0)
+    if (o.has_warp) {
+      transformed_texture(o.tex[0].data(), c.W, c.H, o.motion, o.tex[2].data());
+      std::vector<uint8_t> t;
+      apply_warp(o.tex[2], c.W, c.H, 3, *o.warp, true, t);
+      o.tex[2].swap(t);
+    } else if (o.bb[1][0] <= o.bb[1][2]) {
+      transformed_texture_region(o.tex[0].data(), c.W, c.H, o.motion, o.tex[2].data(), o.bb[1][0], o.bb[1][1], o.bb[1][2], o.bb[1][3]);
+    }
+    return;
+  }
   transformed_texture(o.tex[0].data(), c.W, c.H, Affine(), o.tex[1].data());
   transformed_texture(o.tex[0].data(), c.W, c.H, o.motion, o.tex[2].data());
   if (o.has_warp) {
@@ -312,10 +367,17 @@ void render_textures(const Ctx& c, Object& o) {
 // MovingObjectBackground (DG:654-718)
 void render_background(const Ctx& c, Object& o) {
   const int W = c.W, H = c.H, W2 = 2 * W, H2 = 2 * H;
-  std::vector<uint8_t> t1(o.tex[0].size()), t2(o.tex[0].size());
-  transformed_texture(o.tex[0].data(), W2, H2, Affine(), t1.data());
+  std::vector<uint8_t> t1, t2(o.tex[0].size());
   Affine m = o.intrinsic_inv * o.motion * o.intrinsic;  // DG:673,677
-  transformed_texture(o.tex[0].data(), W2, H2, m, t2.data());
+  if (c.faithful) {
+    t1.resize(o.tex[0].size());
+    transformed_texture(o.tex[0].data(), W2, H2, Affine(), t1.data());
+    transformed_texture(o.tex[0].data(), W2, H2, m, t2.data());
+  } else {  // identity == copy; of the warped texture only the centre crop is ever used (unless a warp field re-samples it)
+    t1 = o.tex[0];
+    if (o.has_warp) transformed_texture(o.tex[0].data(), W2, H2, m, t2.data());
+    else transformed_texture_region(o.tex[0].data(), W2, H2, m, t2.data(), (int)(W / 2.), (int)(H / 2.), (int)(W / 2.) + W - 1, (int)(H / 2.) + H - 1);
+  }
   if (o.has_warp) {
     std::vector<uint8_t> t;
     apply_warp(t2, W2, H2, 3, *o.warp, true, t);
@@ -333,6 +395,7 @@ void render_background(const Ctx& c, Object& o) {
   for (int f = 0; f < 2; ++f) {  // renderMasks, DG:684-690
     o.mask_AA[f].assign((size_t)W * H, 255);
     o.mask_noAA[f].assign((size_t)W * H, 255);
+    full_box(c, o, f);
   }
 }
 
@@ -409,8 +472,33 @@ Object* realize(const Ctx& c, const ofdg_blueprint* bps, int bi, const Affine& b
     }
   }
   // Process_UnfinishedObjectContainer (DG:726-732)
-  if (!parent) render_textures(c, *o);  // Component*::renderTransformedTexture is empty (DG:546-560)
-  if (p.obj_type == OFDG_OBJ_COMPOSITE) {
+  if (!parent && c.faithful) render_textures(c, *o);  // Component*::renderTransformedTexture is empty (DG:546-560)
+  if (p.obj_type == OFDG_OBJ_COMPOSITE && !c.faithful) {
+    // lean: the same sequential fp32 chain, inside the union of the components' boxes (zero elsewhere)
+    const size_t n = (size_t)c.W * c.H;
+    for (int f = 0; f < 2; ++f) {
+      o->mask_AA[f].assign(n, 0); o->mask_noAA[f].assign(n, 0);
+      int x0 = c.W, y0 = c.H, x1 = -1, y1 = -1;
+      for (Object* co : comps)
+        if (co->bb[f][0] <= co->bb[f][2]) { x0 = std::min(x0, co->bb[f][0]); y0 = std::min(y0, co->bb[f][1]); x1 = std::max(x1, co->bb[f][2]); y1 = std::max(y1, co->bb[f][3]); }
+      if (x0 > x1) continue;
+      o->bb[f][0] = x0; o->bb[f][1] = y0; o->bb[f][2] = x1; o->bb[f][3] = y1;
+      for (size_t ci = 0; ci < comps.size(); ++ci) {
+        Object* co = comps[ci];
+        for (int y = y0; y <= y1; ++y)
+          for (int x = x0; x <= x1; ++x) {
+            const size_t i = (size_t)y * c.W + x;
+            if (comp_modes[ci]) {
+              o->mask_noAA[f][i] = composite_add(o->mask_noAA[f][i], co->mask_noAA[f][i]);
+              o->mask_AA[f][i] = composite_add(o->mask_AA[f][i], co->mask_AA[f][i]);
+            } else {
+              o->mask_noAA[f][i] = composite_sub(o->mask_noAA[f][i], co->mask_noAA[f][i]);
+              o->mask_AA[f][i] = composite_sub(o->mask_AA[f][i], co->mask_AA[f][i]);
+            }
+          }
+      }
+    }
+  } else if (p.obj_type == OFDG_OBJ_COMPOSITE) {
     // MovingObjectComposite::renderMasks (DG:591-646)
     const size_t n = (size_t)c.W * c.H;
     for (int f = 0; f < 2; ++f) { o->mask_AA[f].assign(n, 0); o->mask_noAA[f].assign(n, 0); }
@@ -432,6 +520,7 @@ Object* realize(const Ctx& c, const ofdg_blueprint* bps, int bi, const Affine& b
     scene.shape_order.push_back(o);
     render_shape_masks(c, *o, geom_of(p), ok);
   }
+  if (!parent && !c.faithful) render_textures(c, *o);  // (lean: after the masks, whose boxes bound the texture work)
   return o;
 }
 
@@ -474,6 +563,22 @@ bool process_task(const Ctx& c, const ofdg_task& task, const ofdg_blueprint* bps
   std::vector<size_t> index0(n, 0);
   for (auto& kv : scene.objects) {
     const Object& o = *kv.second;
+    if (!c.faithful) {  // lean: the object's boxes only (its masks are zero elsewhere: draw_image leaves d as is)
+      const std::vector<uint8_t>& m0 = c.use_AA ? o.mask_AA[0] : o.mask_noAA[0];
+      const std::vector<uint8_t>& m1 = c.use_AA ? o.mask_AA[1] : o.mask_noAA[1];
+      for (int y = o.bb[0][1]; y <= o.bb[0][3]; ++y)
+        for (int x = o.bb[0][0]; x <= o.bb[0][2]; ++x) {
+          const size_t i = (size_t)y * W + x;
+          if (o.mask_noAA[0][i] == 255) index0[i] = o.id;
+          if (m0[i]) for (int ch = 0; ch < 3; ++ch) frame0[ch * n + i] = draw_image_value(frame0[ch * n + i], o.tex[1][ch * n + i], m0[i]);
+        }
+      for (int y = o.bb[1][1]; y <= o.bb[1][3]; ++y)
+        for (int x = o.bb[1][0]; x <= o.bb[1][2]; ++x) {
+          const size_t i = (size_t)y * W + x;
+          if (m1[i]) for (int ch = 0; ch < 3; ++ch) frame1[ch * n + i] = draw_image_value(frame1[ch * n + i], o.tex[2][ch * n + i], m1[i]);
+        }
+      continue;
+    }
     for (size_t i = 0; i < n; ++i)
       if (o.mask_noAA[0][i] == 255) index0[i] = o.id;
     const std::vector<uint8_t>& m0 = c.use_AA ? o.mask_AA[0] : o.mask_noAA[0];
@@ -634,7 +739,7 @@ int ofdg_oracle_render(const ofdg_params* prm, const ofdg_task* tasks, int n_tas
                        const float* warp_crops, int n_crops, int reuse,
                        float* img0, float* img1, float* flow, int n_threads) {
   (void)n_bps;
-  Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
+  Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, lean_flag() == 0};
   c.background_prep = prm->background_prep != 0;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
   const size_t n = (size_t)c.W * c.H;
@@ -692,6 +797,11 @@ int ofdg_oracle_set_detmath(int on) { const int old = detmath_flag(); detmath_fl
 // the functions themselves (CPU tests: accuracy against libm; GPU tests: device == host bit for bit)
 void ofdg_oracle_det_sincos(const double* a, int n, double* s, double* c) { for (int i = 0; i < n; ++i) ofdg_det_sincos(a[i], s + i, c + i); }
 void ofdg_oracle_det_expf(const float* x, int n, float* y) { for (int i = 0; i < n; ++i) y[i] = ofdg_det_expf(x[i]); }
+
+// CPU-baseline cost model (process-wide; returns the previous value).  0 (default): "faithful" - the reference's
+// work pattern; 1: "lean" - the same output bit for bit with one rasterisation per frame and work restricted to
+// the outlines' boxes.  Parity tests always run the faithful form.
+int ofdg_oracle_set_lean(int on) { const int old = lean_flag(); lean_flag() = on ? 1 : 0; return old; }
 
 int ofdg_oracle_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 

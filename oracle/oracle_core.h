@@ -29,6 +29,7 @@ namespace oracle {
 // include/ofdg_detmath.h, the functions the DEVICE counter-sampler path is defined with (that path
 // has no reference bit stream; see the header).  Set by ofdg_oracle_set_detmath().
 inline int& detmath_flag() { static int f = 0; return f; }
+inline int& lean_flag() { static int f = 0; return f; }  // CPU-baseline cost model, see ofdg_oracle_set_lean
 
 // ---------------------------------------------------------------------------
 // agg::trans_affine (AGG 2.4 agg_trans_affine.h / .cpp), used at
@@ -489,11 +490,14 @@ struct WrapReflect {
 };
 
 // getTransformedTexture (DataGenerator.cpp:168-231): in/out planar u8 [3][th][tw].
-inline void transformed_texture(const uint8_t* in, int tw, int th, const Affine& tf, uint8_t* out) {
+// kRegion (the "lean" CPU baseline only): the same values, but only for the pixels of rows ry0..ry1, columns
+// rx0..rx1 (the reference always renders the full rectangle).
+template <bool kRegion>
+inline void transformed_texture_impl(const uint8_t* in, int tw, int th, const Affine& tf, uint8_t* out, int rx0, int ry0, int rx1, int ry1) {
   Affine inv = tf;
   inv.invert();
   const size_t plane = (size_t)tw * th;
-  for (int y = 0; y < th; ++y) {
+  for (int y = kRegion ? ry0 : 0; y < (kRegion ? ry1 + 1 : th); ++y) {
     // one span per row: x = 0, len = tw (the rendered path is the image rectangle)
     double tx = 0 + 0.5, ty = y + 0.5;
     inv.transform(&tx, &ty);
@@ -503,7 +507,8 @@ inline void transformed_texture(const uint8_t* in, int tw, int th, const Affine&
     int x2 = iround(tx * 256), y2 = iround(ty * 256);
     Dda2 lix(x1, x2, tw), liy(y1, y2, tw);
     WrapReflect wx(tw), wy(th);
-    for (int x = 0; x < tw; ++x) {
+    for (int x = 0; x < (kRegion ? rx1 + 1 : tw); ++x) {
+      if (kRegion && x < rx0) { ++lix; ++liy; continue; }
       int x_hr = lix.y - 128, y_hr = liy.y - 128;
       int x_lr = x_hr >> 8, y_lr = y_hr >> 8;
       unsigned fg[3] = {256 * 256 / 2, 256 * 256 / 2, 256 * 256 / 2};
@@ -526,6 +531,12 @@ inline void transformed_texture(const uint8_t* in, int tw, int th, const Affine&
       ++lix; ++liy;
     }
   }
+}
+inline void transformed_texture(const uint8_t* in, int tw, int th, const Affine& tf, uint8_t* out) {
+  transformed_texture_impl<false>(in, tw, th, tf, out, 0, 0, tw - 1, th - 1);
+}
+inline void transformed_texture_region(const uint8_t* in, int tw, int th, const Affine& tf, uint8_t* out, int rx0, int ry0, int rx1, int ry1) {
+  transformed_texture_impl<true>(in, tw, th, tf, out, rx0, ry0, rx1, ry1);
 }
 
 // CImg<unsigned char>::draw_image(0,0,sprite,mask,1,255) per value

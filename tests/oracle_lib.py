@@ -97,6 +97,7 @@ def lib():
         L.ofdg_oracle_shape_masks.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ofdg_oracle_set_detmath.argtypes = [C.c_int]
+        L.ofdg_oracle_set_lean.argtypes = [C.c_int]
         L.ofdg_oracle_det_sincos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ofdg_oracle_det_expf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -112,6 +113,17 @@ class detmath:
 
     def __exit__(self, *a):
         lib().ofdg_oracle_set_detmath(self.old)
+
+
+class lean:
+    """Context manager: the oracle's "lean" CPU-baseline cost model (one rasterisation per frame, work restricted
+    to the outlines' boxes; same output).  Default and parity tests: the reference's work pattern ("faithful")."""
+
+    def __enter__(self):
+        self.old = lib().ofdg_oracle_set_lean(1)
+
+    def __exit__(self, *a):
+        lib().ofdg_oracle_set_lean(self.old)
 
 
 def det_sincos(a):

@@ -1,0 +1,93 @@
+"""Native multi-GPU start-up (csrc/comm.cpp) on the GPU box: a single-rank RCCL communicator runs the same
+ncclBroadcast code path the 8-GPU job runs (one broadcast of the seed + texture index table, then
+disjoint shards with no data-path collective).  The world-size-2 sharding rules are covered on CPU with gloo
+(tests/test_host_logic.py) and on the GPU by test_forward_shards_across_ranks / test_counter_rank_sharding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm(ofdg):
+    c = ofdg.Comm(ofdg.Comm.unique_id(), 0, 1, 0)
+    yield c
+    c.close()
+
+
+def test_bcast_setup_carries_stream_and_index_table(ofdg, comm):
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=11, num_objects=9, batch_size=4, sampler=1, seed=77))
+    g.pool_synthetic(5, 300, 200, 9)
+    su, table = comm.bcast_setup(g)
+    assert (su.seed, su.mode, su.width, su.height, su.num_objects, su.batch_size, su.sampler) == (77, 11, 128, 96, 9, 4, 1)
+    assert (su.n_tex, su.pool_kind, su.pool_w, su.pool_h, su.pool_seed, su.n_table) == (5, ofdg.POOL_SYNTHETIC, 300, 200, 9, 5)
+    for i in range(5):
+        assert (table[i].offset, table[i].w, table[i].h, table[i].pitch) == (i * 300 * 200, 300, 200, 300)
+    # a receiving rank: context from the header, pool from the header, same samples for the same indices
+    p = comm.params_of(su)
+    assert (p.rank, p.world_size, p.device, p.mode, p.seed) == (0, 1, 0, 11, 77)
+    g2 = ofdg.Generator(p)
+    g2.pool_from_setup(su)
+    assert np.array_equal(g.pool_download_all(), g2.pool_download_all())
+    a, b = ofdg.alloc_outputs(4, 96, 128), ofdg.alloc_outputs(4, 96, 128)
+    g.forward(*a); g.synchronize()
+    g2.forward(*b); g2.synchronize()
+    import torch
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_bcast_pool_replicates_the_resident_pool(ofdg, comm, mixed):
+    """ncclBroadcast between the HBM pools (uniform and mixed-size texture collections); with one rank the
+    root's pool must come through unchanged, and the derived textures must still be valid afterwards."""
+    rng = np.random.RandomState(5)
+    g = ofdg.Generator(ofdg.default_params(width=64, height=48, mode=5, num_objects=4))
+    sizes = [(200, 150), (90, 70), (256, 192)] if mixed else [(200, 150)] * 3
+    if mixed:
+        g.pool_alloc_mixed(3)
+    else:
+        g.pool_alloc(3, 200, 150)
+    imgs = [rng.randint(0, 256, (3, h, w)).astype(np.uint8) for (w, h) in sizes]
+    for i, im in enumerate(imgs):
+        (g.pool_upload_mixed if mixed else g.pool_upload)(i, im)
+    su, table = comm.bcast_setup(g)
+    assert su.pool_kind == (ofdg.POOL_MIXED if mixed else ofdg.POOL_UNIFORM) and su.n_table == 3
+    assert [(table[i].w, table[i].h) for i in range(3)] == sizes
+    hs = ofdg.HostSampler(5, 64, 48, 4)
+    tasks, bps, n = hs.next(2)
+    before = ofdg.alloc_outputs(2, 48, 64)
+    g.render(tasks, 2, bps, n, *before); g.synchronize()
+    comm.bcast_pool(g)
+    after = ofdg.alloc_outputs(2, 48, 64)
+    g.render(tasks, 2, bps, n, *after); g.synchronize()
+    import torch
+    assert all(torch.equal(x, y) for x, y in zip(before, after))
+
+
+def test_layer_on_a_communicator(ofdg, comm, tmp_path):
+    """ofdg_layer_create_dist: the C++ DataGenerationLayer shards by itself - options and texture collection of
+    rank 0 are broadcast, rank / world_size / device come from the communicator."""
+    import torch
+    proto = """layer { name: "d" type: "DataGeneration" top: "a" top: "b" top: "f"
+      data_param { batch_size: 2 prefetch: 2 }
+      data_generation_param { mode: 7 texture_dbases: "synthetic:3:256:192:4" width: 128 height: 96 sampler: counter seed: 3 } }"""
+    one = ofdg.DataGenerationLayer(proto)
+    dist = ofdg.DataGenerationLayer(proto, comm)
+    for _ in range(3):
+        x, y = one.Forward(), dist.Forward()
+        assert all(torch.equal(a, b) for a, b in zip(x, y))
+    one.close(); dist.close()
+
+
+def test_comm_joins_through_a_key_value_store(ofdg):
+    """bench.py's start-up for N > 1: rank 0 publishes the ncclUniqueId in the launcher's store, every rank joins
+    (here: the one rank of a single-GPU box, through an in-process torch.distributed.HashStore)."""
+    import torch.distributed as dist
+    store = dist.HashStore()
+    c = ofdg.Comm.from_store(store, 0, 1, 0)
+    assert len(bytes(store.get("ofdg_unique_id"))) == ofdg.UNIQUE_ID_BYTES
+    g = ofdg.Generator(ofdg.default_params(width=64, height=48, mode=5, sampler=1, seed=5))
+    g.pool_synthetic(2, 128, 96, 1)
+    su, table = c.bcast_setup(g)
+    assert su.n_table == 2 and su.seed == 5
+    c.close()

@@ -364,6 +364,24 @@ def test_layer_prefetch_ring_yields_the_same_batches(ofdg):
         assert not torch.equal(seqs[0][0][0], seqs[0][1][0])   # (consecutive batches differ)
 
 
+def test_layer_forward_waits_for_the_oldest_batch_only(ofdg, monkeypatch):
+    """prefetch: 4 - Forward returns when the OLDEST set's event has fired (prefetch_full_.pop,
+    data_generation_layer.cpp:266-282) while the batches rendered behind it are still in flight.  One internal
+    chain, so that the three batches of 128 x 512x384 samples queued ahead finish one after the other (~0.5 ms
+    apart) and the state at the return of Forward is unambiguous."""
+    monkeypatch.setenv("OFDG_CHAINS", "1")
+    proto = """layer { name: "d" type: "DataGeneration" top: "a" top: "b" top: "f"
+      data_param { batch_size: 128 prefetch: 4 }
+      data_generation_param { mode: 7 texture_dbases: "synthetic:16:1024:768:4" sampler: counter seed: 3 } }"""
+    layer = ofdg.DataGenerationLayer(proto)
+    seen = []
+    for _ in range(6):
+        layer.Forward()           # (copies the tops out: the layer keeps rendering meanwhile)
+        seen.append(layer.in_flight())
+    layer.close()
+    assert max(seen) >= 2, seen   # two later batches were still rendering when a Forward returned
+
+
 def test_forward_shards_across_ranks(ofdg, oracle):
     """ofdg_forward with rank/world_size: rank r renders block r of every B*world tasks."""
     W, H, B = 128, 96, 2

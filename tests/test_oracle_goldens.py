@@ -212,3 +212,30 @@ def test_end_to_end_fixture_pins_the_oracle(oracle):
         i0, i1, fl = gen.scene(sc["mode"], sc["use_antialiasing"])
         assert gen.digest(i0) == sc["image0"] and gen.digest(i1) == sc["image1"], sc["mode"]
         assert gen.digest(fl) == sc["flow"], sc["mode"]
+
+
+def test_lean_cost_model_renders_the_same_bytes(oracle):
+    """The "lean" CPU-baseline form of the oracle (one rasterisation per frame, work restricted to the outlines'
+    boxes) must be a pure cost model: the fixture's twelve scenes and two full-size samples come out
+    bit for bit as in the reference's work pattern."""
+    import importlib.util, json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_e2e_goldens", os.path.join(here, "gen_e2e_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fix = json.load(open(os.path.join(here, "e2e_hashes.json")))
+    with oracle.lean():
+        for sc in fix["scenes"]:
+            i0, i1, fl = gen.scene(sc["mode"], sc["use_antialiasing"])
+            assert gen.digest(i0) == sc["image0"] and gen.digest(i1) == sc["image1"] and gen.digest(fl) == sc["flow"], sc["mode"]
+    rng = np.random.RandomState(1)
+    pool = rng.randint(0, 256, (3, 3, 768, 1024)).astype(np.uint8)
+    for mode in (5, 7):
+        s = oracle.Sampler(mode, 512, 384)
+        tasks, bps, n = s.next(1)
+        prm = oracle.default_params(512, 384, mode, 1, 1, 0)
+        want = oracle.render(prm, tasks, 1, bps, n, pool)
+        with oracle.lean():
+            got = oracle.render(prm, tasks, 1, bps, n, pool)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), mode

@@ -79,7 +79,7 @@ def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128):
 
     def run(n_threads, lean, budget):
         n = max(n_threads, 2)
-        tasks, bps, n_bps = sampler.next(n, cap=n * 64)
+        tasks, bps, n_bps = sampler.next(n, cap=n * 320)
         done, t0 = 0, time.perf_counter()
         while True:
             if lean:

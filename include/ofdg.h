@@ -110,9 +110,12 @@ typedef struct ofdg_params {
   int32_t device;               /* HIP device ordinal */
   int32_t max_shapes_per_sample;/* 0 = default capacity */
   int32_t background_prep;      /* background texture m_textures[0] (DG:1186-1192):
-                                   0 = centre 2W x 2H crop of the pool image (parity boundary, default);
-                                   1 = Texture::getRandomizedCrop(2W, 2H, tex_rot, tex_scale, tex_shift)
-                                       (DG:87-109): shift, rotate, centre crop, zoom (CImg chain, unpinned) */
+                                   0 = centre 2W x 2H crop of the pool image (the C-ABI default; parity boundary of round 1);
+                                   1 = Texture::getRandomizedCrop(2W, 2H, tex_rot, tex_scale, tex_shift) (DG:87-109) the way
+                                       CImg runs it: get_shift -> rotate (linear, mirror, grown canvas) -> u8 -> crop (float ->
+                                       int truncation, mirror) -> resize (per axis linear / moving average, u8 in between);
+                                   2 = the same geometry as ONE resampling along the composed coordinate map (fast form:
+                                       one interpolation less of blur, values differ from 1).  CImg itself: parity unpinned */
   int32_t reserved[8];
 } ofdg_params;
 

@@ -1877,11 +1877,10 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
   if (m < 0) m += 2 * n;
   return m < n ? m : 2 * n - m - 1;
 }
-// one prepared texel (strict fp32, the oracle's operation order)
-__device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, int u, int v) {
+// R(x, y) of CImg's rotate(angle, 1, 3) for xc = x - rw2, yc = y - rh2, on the SHIFTED pool image (strict fp32, the
+// oracle's operation order): mirrored float coordinates, _linear_atXY (Neumann), truncation to u8 per channel
+__device__ __forceinline__ uint32_t bgprep_rot_sample(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, float xc, float yc) {
   const float ww = 2.0f * pw, hh = 2.0f * ph;
-  const float cxf = fminf((float)(p.cw - 1), __fmul_rn((float)u, p.fx)), cyf = fminf((float)(p.ch - 1), __fmul_rn((float)v, p.fy));
-  const float xc = __fsub_rn(__fadd_rn((float)p.x0, cxf), p.rw2), yc = __fsub_rn(__fadd_rn((float)p.y0, cyf), p.rh2);
   float mx = __fadd_rn(__fadd_rn(p.w2, __fmul_rn(xc, p.ca)), __fmul_rn(yc, p.sa));
   float my = __fadd_rn(__fsub_rn(p.h2, __fmul_rn(xc, p.sa)), __fmul_rn(yc, p.ca));
   if (!(mx >= 0.f && mx < ww)) mx = cimg_modf(mx, ww);  // (cimg::mod is the identity on [0, m))
@@ -1914,6 +1913,139 @@ __device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, const uint3
   }
   return out;
 }
+// background_prep = 2 (fast form): one prepared texel by ONE resampling along the composed coordinate map
+__device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, int u, int v) {
+  const float cxf = fminf((float)(p.cw - 1), __fmul_rn((float)u, p.fx)), cyf = fminf((float)(p.ch - 1), __fmul_rn((float)v, p.fy));
+  const float xc = __fsub_rn(__fadd_rn((float)p.x0, cxf), p.rw2), yc = __fsub_rn(__fadd_rn((float)p.y0, cyf), p.rh2);
+  return bgprep_rot_sample(p, img, pw, ph, xc, yc);
+}
+
+// ---- background_prep = 1: the CImg chain stage by stage (DG:96-103), four u8 images -------------------------------
+//   C = crop(rotate(shift(T)))  cw x ch   bgprep_rotcrop_kernel (shift, rotate and crop are per-texel maps: fused, exact)
+//   M = resize of C along x     2W x ch   bgprep_resize_kernel<true>
+//   B = resize of M along y     2W x 2H   bgprep_resize_kernel<false>  -> the sample's background texture
+// Only what compose can read of B (DevBgPrep.r*) is produced, and of M and C what that needs (DevBgPlan).
+struct DevBgPlan {
+  int32_t cx0, cx1;  // columns of C the X pass reads
+  int32_t my0, my1;  // rows of M (= rows of C) the Y pass reads
+  int32_t ok, pad[3];
+};
+// CImg get_resize(.., 3), enlarging: source index and weight of every destination pixel - running double sums
+// (curr = min(n - 1, curr + f)), sequential by definition: one lane per (sample, axis)
+__device__ inline void cimg_enlarge_table(int n, int s, int* __restrict__ at, double* __restrict__ alpha) {
+  const double f = s > 1 ? (n - 1.) / (s - 1) : 0;
+  double curr = 0, old = 0;
+  int pos = 0;
+  for (int x = 0; x < s; ++x) {
+    alpha[x] = curr - (double)(unsigned int)curr;
+    at[x] = pos;
+    old = curr;
+    curr = fmin(n - 1., curr + f);
+    pos += (int)((unsigned int)curr - (unsigned int)old);
+  }
+}
+// source range [lo, hi] a resize pass reads for destination pixels d0..d1 (n source, s destination pixels)
+__device__ inline void cimg_resize_range(int n, int s, int d0, int d1, const int* __restrict__ at, int* lo, int* hi) {
+  if (s > n) { *lo = at[d0]; *hi = min(at[d1] + 1, n - 1); }
+  else if (s == n) { *lo = d0; *hi = d1; }
+  else { *lo = (int)(((long long)d0 * n) / s); *hi = (int)((((long long)(d1 + 1)) * n - 1) / s); }
+}
+__global__ __launch_bounds__(64) void bgprep_plan_kernel(const DevBgPrep* __restrict__ prep, int W, int H, int cap_cw, int cap_ch,
+                                                         int* __restrict__ at, double* __restrict__ alpha, DevBgPlan* __restrict__ plan,
+                                                         uint32_t* __restrict__ err) {
+  const int s = blockIdx.x, TW = 2 * W, TH = 2 * H;
+  const DevBgPrep p = prep[s];
+  int* at_x = at + (size_t)s * (TW + TH);
+  int* at_y = at_x + TW;
+  double* al_x = alpha + (size_t)s * (TW + TH);
+  double* al_y = al_x + TW;
+  const bool fits = p.cw >= 1 && p.ch >= 1 && p.cw <= cap_cw && p.ch <= cap_ch;
+  if (fits) {
+    if (threadIdx.x == 0 && p.cw < TW) cimg_enlarge_table(p.cw, TW, at_x, al_x);
+    if (threadIdx.x == 1 && p.ch < TH) cimg_enlarge_table(p.ch, TH, at_y, al_y);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DevBgPlan q = DevBgPlan();
+    q.ok = fits ? 1 : 0;
+    if (fits) {
+      cimg_resize_range(p.ch, TH, p.ry0, p.ry1, at_y, &q.my0, &q.my1);
+      cimg_resize_range(p.cw, TW, p.rx0, p.rx1, at_x, &q.cx0, &q.cx1);
+    } else {
+      atomicOr(err, kErrBgPrepCapacity);
+    }
+    plan[s] = q;
+  }
+}
+// C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y
+__global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, const DevBgPlan* __restrict__ plan,
+                                                             const uint32_t* __restrict__ pool, int pw, int ph, int cap_cw, int cap_ch,
+                                                             uint32_t* __restrict__ C) {
+  const int s = blockIdx.y;
+  const DevBgPlan q = plan[s];
+  if (!q.ok) return;
+  const int rw_ = q.cx1 - q.cx0 + 1, rh_ = q.my1 - q.my0 + 1;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= rw_ * rh_) return;
+  const int j = q.my0 + k / rw_, i = q.cx0 + k % rw_;
+  const DevBgPrep p = prep[s];
+  const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+  const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+  C[(size_t)s * cap_cw * cap_ch + (size_t)j * p.cw + i] = bgprep_rot_sample(p, pool + p.image_base, pw, ph, xc, yc);
+}
+// one axis of CImg's linear get_resize on BGRX texels (see pool_resize_axis_kernel): kAlongX: C (cw x ch) -> M (2W x ch);
+// else M -> B (2W x 2H), the sample's texture
+template <bool kAlongX>
+__global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __restrict__ prep, const DevBgPlan* __restrict__ plan,
+                                                            const int* __restrict__ at, const double* __restrict__ alpha, int W, int H,
+                                                            int cap_cw, int cap_ch, const uint32_t* __restrict__ src_all,
+                                                            uint32_t* __restrict__ dst_all) {
+  const int s = blockIdx.y, TW = 2 * W, TH = 2 * H;
+  const DevBgPlan q = plan[s];
+  if (!q.ok) return;
+  const DevBgPrep p = prep[s];
+  // destination region
+  const int dx0 = p.rx0, dx1 = p.rx1, dy0 = kAlongX ? q.my0 : p.ry0, dy1 = kAlongX ? q.my1 : p.ry1;
+  const int rw_ = dx1 - dx0 + 1, rh_ = dy1 - dy0 + 1;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= rw_ * rh_) return;
+  const int y = dy0 + k / rw_, x = dx0 + k % rw_;
+  const int n = kAlongX ? p.cw : p.ch, sdim = kAlongX ? TW : TH;  // source / destination length along the axis
+  const int sw = kAlongX ? p.cw : TW;                                 // source row pitch
+  const uint32_t* src = src_all + (kAlongX ? (size_t)s * cap_cw * cap_ch : (size_t)s * TW * cap_ch);
+  uint32_t* dst = dst_all + (kAlongX ? (size_t)s * TW * cap_ch : (size_t)s * TW * TH);
+  const int kk = kAlongX ? x : y, line = kAlongX ? y : x;
+  auto texel = [&](int j) { return kAlongX ? src[(size_t)line * sw + j] : src[(size_t)j * sw + line]; };
+  const int* tab = at + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
+  const double* al_tab = alpha + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
+  uint32_t out = 0;
+  if (sdim == n) {
+    out = texel(kk);
+  } else if (sdim > n) {
+    const int a0 = tab[kk];
+    const double al = al_tab[kk];
+    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
+      out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+    }
+  } else {
+    float acc[3] = {0.f, 0.f, 0.f};
+    const long long lo = (long long)kk * n, hi = lo + n;
+    for (int j = (int)(lo / sdim); (long long)j * sdim < hi; ++j) {
+      const long long a = (long long)j * sdim, b = a + sdim;
+      const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
+      const uint32_t t = texel(j);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
+  }
+  dst[(size_t)y * TW + x] = out;
+}
+
 // one thread = 4 consecutive texels of a row of sample blockIdx.y's texture; texels outside the
 // sample's read region (DevBgPrep.r*) are skipped - compose never looks at them
 __global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, const uint32_t* __restrict__ pool,

@@ -146,7 +146,8 @@ void parse_message(Lexer& lx, const std::string& scope, LayerConfig* cfg, bool t
       else if (f == "height") p.height = to_int(v, key);
       else if (f == "num_objects") p.num_objects = to_int(v, key);
       else if (f == "seed") p.seed = to_int(v, key);
-      else if (f == "background_prep") p.background_prep = (v.text == "true" || v.text == "1") ? 1 : 0;
+      else if (f == "background_prep")  // true / 1: the CImg chain stage by stage; fast / 2: one resampling; false / 0: centre crop
+        p.background_prep = (v.text == "true" || v.text == "1") ? 1 : (v.text == "fast" || v.text == "2") ? 2 : 0;
       else if (f == "sampler") p.sampler = (v.text == "counter") ? OFDG_SAMPLER_COUNTER : OFDG_SAMPLER_REF;
       else throw std::runtime_error("prototxt: unknown data_generation_param field '" + f + "'");
     }

@@ -73,6 +73,11 @@ struct ofdg_ctx {
     DevBuf<int4> d_items;
     DevBuf<DevBgPrep> d_bgprep;   // background_prep: one record ...
     DevBuf<uint32_t> d_bgtex;     // ... and one prepared 2W x 2H BGRX texture per sample
+    // background_prep = 1 (the CImg chain stage by stage): crop of the rotated image, X-resized image, resize tables, plan
+    DevBuf<uint32_t> d_bgC, d_bgM;
+    DevBuf<int> d_bg_at;
+    DevBuf<double> d_bg_alpha;
+    DevBuf<DevBgPlan> d_bgplan;
     DevBuf<unsigned long long> d_blockmask;  // [2 parities][samples][64 x 8 blocks][2 frames]
     int res_objects = 0;
     int box_parity = 0;
@@ -297,6 +302,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   auto drop_slot = [](ofdg_ctx::Slot& sl) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
+    sl.d_bgC.release(); sl.d_bgM.release(); sl.d_bg_at.release(); sl.d_bg_alpha.release(); sl.d_bgplan.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
@@ -857,15 +863,39 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
 // background_prep: (upload the records of n samples and) render their 2W x 2H background
 // textures into the slot's buffer on stream `s` (bgprep_kernel)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s) {
-  const int W = c->prm.width, H = c->prm.height;
+  const int W = c->prm.width, H = c->prm.height, TW = 2 * W, TH = 2 * H;
   HIP_OK(c, sl.d_bgprep.reserve(n));
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
+  // workspace of the staged chain: crops of the rotated image up to zoom 0.75 (the sampler draws 0.8 .. 1.2), or the whole
+  // rotated image when the pool images are smaller than 2W x 2H (DG:102-106; rotation by up to +-3.2 "degrees")
+  int cap_cw = (int)((float)TW / 0.75f) + 2, cap_ch = (int)((float)TH / 0.75f) + 2;
+  if (c->pool_w < TW || c->pool_h < TH) { cap_cw = c->pool_w + c->pool_h / 8 + 4; cap_ch = c->pool_h + c->pool_w / 8 + 4; }
+  const bool staged = c->prm.background_prep == 1;
+  if (staged) {
+    HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
+    HIP_OK(c, sl.d_bgM.reserve((size_t)n * TW * cap_ch));
+    HIP_OK(c, sl.d_bg_at.reserve((size_t)n * (TW + TH)));
+    HIP_OK(c, sl.d_bg_alpha.reserve((size_t)n * (TW + TH)));
+    HIP_OK(c, sl.d_bgplan.reserve(n));
+  }
   if (host_records) {
     HIP_OK(c, hipMemcpyAsync(sl.d_bgprep.p, host_records, (size_t)n * sizeof(DevBgPrep), hipMemcpyHostToDevice, s));
     HIP_OK(c, hipStreamSynchronize(s));  // (pageable source owned by the caller's batch)
   }
-  hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
-                     sl.d_bgtex.p);
+  if (!staged) {
+    hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
+                       sl.d_bgtex.p);
+    HIP_OK(c, hipGetLastError());
+    return OFDG_OK;
+  }
+  hipLaunchKernelGGL(bgprep_plan_kernel, dim3(n), dim3(64), 0, s, sl.d_bgprep.p, W, H, cap_cw, cap_ch, sl.d_bg_at.p, sl.d_bg_alpha.p,
+                     sl.d_bgplan.p, c->d_err);
+  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3((cap_cw * cap_ch + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, c->pool,
+                     c->pool_w, c->pool_h, cap_cw, cap_ch, sl.d_bgC.p);
+  hipLaunchKernelGGL(bgprep_resize_kernel<true>, dim3((TW * cap_ch + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
+                     sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgC.p, sl.d_bgM.p);
+  hipLaunchKernelGGL(bgprep_resize_kernel<false>, dim3((TW * TH + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
+                     sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgM.p, sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
   return OFDG_OK;
 }
@@ -1172,6 +1202,7 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
     if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
     if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
     if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
+    if (e & kErrBgPrepCapacity) c->err += " background_prep: crop of the rotated image exceeds the workspace (zoom < 0.75);";
     return OFDG_ECAPACITY;
   }
   return OFDG_OK;
@@ -1193,6 +1224,7 @@ int ofdg_poll_errors(ofdg_ctx* c) {
     if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
     if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
     if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
+    if (e & kErrBgPrepCapacity) c->err += " background_prep: crop of the rotated image exceeds the workspace (zoom < 0.75);";
     return OFDG_ECAPACITY;
   }
   return OFDG_OK;

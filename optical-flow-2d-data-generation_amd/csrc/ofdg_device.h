@@ -18,6 +18,7 @@ constexpr int kRasterGrid = 512;    // x4 persistent single-wave raster workgrou
 constexpr uint32_t kErrVertCapacity = 1u;   // outline has more than kMaxVerts vertices
 constexpr uint32_t kErrCurveCapacity = 2u;  // a curve exceeded kCurveMaxPts / kCurveMaxDepth
 constexpr uint32_t kErrDxLimit = 4u;        // an edge spans >= 16384 px (AGG dx_limit)
+constexpr uint32_t kErrBgPrepCapacity = 8u; // background_prep: a crop of the rotated image exceeds the workspace (zoom < 0.75)
 
 // 2x3 affine in AGG's member order (sx, shy, shx, sy, tx, ty), fp64.
 struct Mat {
@@ -104,6 +105,7 @@ struct DevBgPrep {
   int32_t shx, shy;        // get_shift offsets
   uint64_t image_base;     // texel offset of the pool image
   int32_t rx0, ry0, rx1, ry1;  // texels of the 2W x 2H texture compose can read (inclusive); the rest is not rendered
+  int32_t rw, rh;              // size of the rotated image (crop coordinates are mirrored into it)
 };
 
 // Where an object's texture lives relative to a pool pointer: image i starts at i * stride, its

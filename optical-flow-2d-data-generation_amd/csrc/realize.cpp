@@ -41,6 +41,7 @@ DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, in
   const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
   p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
   p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
+  p.rw = rw; p.rh = rh;
   if (pw >= TW && ph >= TH) {
     p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
     const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);

@@ -137,6 +137,7 @@ std::vector<uint8_t> centre_crop(const Pool& pool, int raw_index, int cw, int ch
 struct BgPrep {
   float ca, sa, w2, h2, rw2, rh2, fx, fy;
   int x0, y0, cw, ch, shx, shy;
+  int rw, rh;  // size of the rotated image
 };
 inline float cimg_modf(float x, float m) { return (float)(x - m * std::floor((double)x / m)); }
 inline int cimg_modi(int x, int m) { const int r = x % m; return r < 0 ? r + m : r; }
@@ -151,6 +152,7 @@ BgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int s
   const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);
   p.w2 = 0.5f * (pw - 1); p.h2 = 0.5f * (ph - 1);
   p.rw2 = 0.5f * (rw - 1); p.rh2 = 0.5f * (rh - 1);
+  p.rw = rw; p.rh = rh;
   if (pw >= TW && ph >= TH) {
     p.x0 = pw / 2 - TW / 2; p.y0 = ph / 2 - TH / 2;
     const int x1 = (int)((float)p.x0 + (float)TW / zoom - 1.0f), y1 = (int)((float)p.y0 + (float)TH / zoom - 1.0f);
@@ -198,6 +200,52 @@ std::vector<uint8_t> prepared_background(const Pool& pool, int raw_index, int W,
   return out;
 }
 
+// The same chain the way CImg 2.x really runs it (ofdg_params.background_prep = 1; recalled source, SURVEY
+// App. C - PARITY UNPINNED): four images, each rounded to unsigned char before the next stage.
+//   S = get_shift(sx, sy, 0, 0, 3)   = get_crop(-sx, -sy, w-sx-1, h-sy-1, 3): S(i,j) = T(mirror(i-sx), mirror(j-sy))
+//   R = S.rotate(angle, 1, 3)        rw x rh = round(1 + |(w-1)ca| + |(h-1)sa|) x round(1 + |(w-1)sa| + |(h-1)ca|);
+//                                    R(x,y) = (uchar)S._linear_atXY(mirror_f(w2 + xc*ca + yc*sa), mirror_f(h2 - xc*sa + yc*ca)),
+//                                    xc = x - rw2, yc = y - rh2  (angle == 0 mod 360: R = S, which the formula also yields)
+//   C = R.crop(x0, y0, x1, y1, 3)    cw x ch, C(i,j) = R(mirror(x0+i), mirror(y0+j)) (the crop leaves R when zoom < 1)
+//   B = C.resize(2W, 2H, -100, -100, 3): per axis - enlarging: linear (running double sums), shrinking: moving
+//                                    average, same size: copy; unsigned char between the X and the Y pass.
+std::vector<uint8_t> prepared_background_two_pass(const Pool& pool, int raw_index, int W, int H, float angle, float zoom, int shx, int shy) {
+  const int TW = 2 * W, TH = 2 * H, pw = pool.w, ph = pool.h;
+  const BgPrep p = make_bg_prep(pw, ph, W, H, angle, zoom, shx, shy);
+  const int rw = p.rw, rh = p.rh;
+  const uint8_t* t = pool.tex(raw_index);
+  const float ww = 2.0f * pw, hh = 2.0f * ph;
+  auto sxm = [&](int i) { const int m = cimg_modi(i - p.shx, 2 * pw); return m < pw ? m : 2 * pw - m - 1; };
+  auto sym = [&](int j) { const int m = cimg_modi(j - p.shy, 2 * ph); return m < ph ? m : 2 * ph - m - 1; };
+  std::vector<uint8_t> out((size_t)3 * TW * TH);
+  std::vector<uint8_t> C((size_t)p.cw * p.ch);
+  for (int c = 0; c < 3; ++c) {
+    const uint8_t* pl = t + (size_t)c * pw * ph;
+    for (int j = 0; j < p.ch; ++j)
+      for (int i = 0; i < p.cw; ++i) {
+        int rx = cimg_modi(p.x0 + i, 2 * rw), ry = cimg_modi(p.y0 + j, 2 * rh);
+        rx = rx < rw ? rx : 2 * rw - rx - 1;
+        ry = ry < rh ? ry : 2 * rh - ry - 1;
+        const float xc = (float)rx - p.rw2, yc = (float)ry - p.rh2;
+        float mx = cimg_modf((p.w2 + xc * p.ca) + yc * p.sa, ww), my = cimg_modf((p.h2 - xc * p.sa) + yc * p.ca, hh);
+        mx = mx < (float)pw ? mx : (ww - mx) - 1.0f;
+        my = my < (float)ph ? my : (hh - my) - 1.0f;
+        const float nfx = mx <= 0 ? 0.f : (mx >= (float)(pw - 1) ? (float)(pw - 1) : mx);
+        const float nfy = my <= 0 ? 0.f : (my >= (float)(ph - 1) ? (float)(ph - 1) : my);
+        const int x = (int)nfx, y = (int)nfy;
+        const float dx = nfx - x, dy = nfy - y;
+        const int nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
+        const int xa = sxm(x), xb = sxm(nx), ya = sym(y), yb = sym(ny);
+        const float Icc = pl[(size_t)ya * pw + xa], Inc = pl[(size_t)ya * pw + xb];
+        const float Icn = pl[(size_t)yb * pw + xa], Inn = pl[(size_t)yb * pw + xb];
+        C[(size_t)j * p.cw + i] = (uint8_t)(Icc + dx * (Inc - Icc + dy * (Icc + Inn - Icn - Inc)) + dy * (Icn - Icc));
+      }
+    const std::vector<uint8_t> B = cimg_resize_u8(C.data(), p.cw, p.ch, TW, TH);
+    std::memcpy(&out[(size_t)c * TW * TH], B.data(), B.size());
+  }
+  return out;
+}
+
 ShapeGeom geom_of(const ofdg_blueprint& p) {  // DG:1073-1117
   ShapeGeom g;
   g.type = p.obj_type;
@@ -234,7 +282,9 @@ struct Ctx {
   // baseline only, same output bit for bit): one rasterisation per frame, work restricted to the outline's box,
   // identity warps are copies, objects entirely off-screen are skipped.
   bool faithful;
-  bool background_prep = false;  // Texture::getRandomizedCrop with the sampled rotation / zoom / shift (DG:1186-1192)
+  // Texture::getRandomizedCrop with the sampled rotation / zoom / shift (DG:1186-1192): 0 off (centre crop),
+  // 1 the CImg chain stage by stage (four u8 images), 2 one resampling along the composed coordinate map
+  int background_prep = 0;
 };
 
 void set_intrinsic(Object& o, float alpha, float xs, float ys) {  // DG:302-310
@@ -541,7 +591,8 @@ bool process_task(const Ctx& c, const ofdg_task& task, const ofdg_blueprint* bps
     bg->id = pb.obj_id;
     bg->is_background = true;
     set_intrinsic(*bg, 0.f, W, H);  // DG:662
-    bg->tex[0] = c.background_prep ? prepared_background(pool, pb.tex_id, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y)
+    bg->tex[0] = c.background_prep == 1 ? prepared_background_two_pass(pool, pb.tex_id, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y)
+               : c.background_prep ? prepared_background(pool, pb.tex_id, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y)
                                    : centre_crop(pool, pb.tex_id, 2 * W, 2 * H);
     set_motion(*bg, pb.rot, pb.scale, pb.trans_x, pb.trans_y);
     if (c.mode == 9 and pb.do_warpfield_deformation) {  // DG:1194-1202
@@ -740,7 +791,7 @@ int ofdg_oracle_render(const ofdg_params* prm, const ofdg_task* tasks, int n_tas
                        float* img0, float* img1, float* flow, int n_threads) {
   (void)n_bps;
   Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, lean_flag() == 0};
-  c.background_prep = prm->background_prep != 0;
+  c.background_prep = prm->background_prep;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
   const size_t n = (size_t)c.W * c.H;
   WarpSource warps(warp_crops, n_crops, c.W + 1, c.H + 1, reuse);
@@ -772,7 +823,7 @@ int ofdg_oracle_shape_masks(const ofdg_params* prm, const ofdg_task* task, const
                             const uint8_t* pool_data, int pool_n, int pool_w, int pool_h,
                             uint8_t* masks, int max_shapes) {
   Ctx c{prm->width, prm->height, prm->mode, prm->use_antialiasing != 0, true};
-  c.background_prep = prm->background_prep != 0;
+  c.background_prep = prm->background_prep;
   Pool pool{pool_n, pool_w, pool_h, pool_data};
   const size_t n = (size_t)c.W * c.H;
   std::vector<float> a(3 * n), b(3 * n), f(2 * n);

@@ -126,6 +126,37 @@ def test_rasteriser_offscreen_and_clipped(ofdg, oracle):
         assert np.array_equal(cov, exp), "case %d: %d px differ" % (i, (cov != exp).sum())
 
 
+def test_rasteriser_long_edges_take_the_wide_arithmetic(ofdg, oracle):
+    """Edges spanning 8 192 .. 16 383 px leave the 32-bit fast path of the closed-form cell stepping (64-bit / fp64
+    quotients, csrc/kernels.hip edge_scanline / hline slow halves); AGG itself walks them incrementally in int32
+    (the oracle).  Shapes far larger than the frame, crossing it at shallow and steep angles; bit-exact.  (matplotlib's
+    AGG clips such paths in double precision before the integer rasteriser sees them, so it cannot pin this case.)"""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 5)
+    rng = np.random.RandomState(11)
+    cases = []
+    for i in range(60):
+        L = rng.uniform(8300, 16000)                     # edge length in px (dx_limit is 16 384)
+        a = rng.uniform(0, 2 * np.pi) if i % 3 else rng.choice([0.001, 1.5697, 3.1409, 0.0302])
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)    # the long edge passes through the frame
+        t = rng.uniform(0.2, 0.8)
+        p0 = np.array([cx - t * L * np.cos(a), cy - t * L * np.sin(a)])
+        p1 = np.array([cx + (1 - t) * L * np.cos(a), cy + (1 - t) * L * np.sin(a)])
+        n = np.array([-np.sin(a), np.cos(a)]) * rng.uniform(3, 3000)
+        cases.append(np.stack([p0, p1, p1 + n, p0 + n * rng.uniform(0.2, 1.0)]))
+    cases.append(np.array([[-8000.0, -3.3], [8200, 40.7], [8200, 90.1], [-8000, 60.2]]))   # near-horizontal, both ends far out
+    cases.append(np.array([[30.2, -7000.0], [90.6, 9000], [70.1, 9000], [10.9, -7000]]))   # near-vertical
+    cases.append(np.array([[-6000.0, -6000], [6000.5, 6100.25], [5900, 6300], [-6100, -5800]]))  # diagonal
+    differing = 0
+    for i, xy in enumerate(cases):
+        cov = g.debug_rasterize(xy)
+        exp = oracle.rasterize(xy, W, H)
+        assert np.array_equal(cov, exp), "case %d: %d px differ" % (i, (cov != exp).sum())
+        differing += int(exp.any())
+    assert differing >= len(cases) // 2     # (the cases do cover pixels of the frame)
+    g.synchronize()                          # no capacity / dx_limit flag was raised
+
+
 @pytest.mark.parametrize("size", [(128, 96), (160, 100)], ids=["128x96-pow2-kernel", "160x100-any-width-kernel"])
 @pytest.mark.parametrize("mode", [1, 2, 3, 5, 7, 13])
 def test_render_matches_oracle_small(ofdg, oracle, mode, size):
@@ -502,22 +533,26 @@ def test_mode9_full_size_generated_fields(ofdg):
 
 
 # ---- background texture preparation (CImg chain restated, parity unpinned) ----
+@pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
 @pytest.mark.parametrize("mode,size,pool", [(5, (128, 96), (5, 256, 192)), (7, (128, 96), (3, 320, 260)), (5, (160, 100), (3, 384, 256))])
-def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool):
-    """background_prep = 1: every sample's 2W x 2H background texture is getRandomizedCrop(2W, 2H, rot, zoom,
-    shift) of its pool image (bgprep_kernel) - bit-exact against the oracle's restatement, pool images equal to
-    and larger than 2W x 2H (zoom < 1 then reads beyond the image: mirror)."""
+def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool, prep):
+    """background_prep: every sample's 2W x 2H background texture is getRandomizedCrop(2W, 2H, rot, zoom, shift) of
+    its pool image - 1: the CImg chain stage by stage (rotate -> u8 -> crop -> resize per axis with u8 in between;
+    bgprep_rotcrop / bgprep_resize kernels), 2: one resampling (bgprep_kernel) - bit-exact against the oracle's
+    restatement of each, pool images equal to and larger than 2W x 2H (zoom < 1 then reads beyond the rotated
+    image: mirror)."""
     W, H = size
-    p = ofdg.default_params(width=W, height=H, mode=mode, background_prep=1)
+    p = ofdg.default_params(width=W, height=H, mode=mode, background_prep=prep)
     g = ofdg.Generator(p)
     g.pool_synthetic(pool[0], pool[1], pool[2], 9)
     host_pool = g.pool_download_all()
     tasks, bps, n = oracle.Sampler(mode, W, H).next(5)
     got = render_gpu(ofdg, g, tasks, 5, bps, n)
     q = params_for_oracle(oracle, p)
-    q.background_prep = 1
+    q.background_prep = prep
     e0, e1, ef = oracle.render(q, tasks, 5, bps, n, host_pool)
-    assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
     assert ulp_diff(got[2], ef).max() == 0
     # and it is not the centre crop: the preparation changes the frames
     q.background_prep = 0
@@ -525,16 +560,17 @@ def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool):
     assert (c0 != e0).mean() > 0.02
 
 
-def test_background_prep_full_size_and_counter_sampler(ofdg, oracle):
+@pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
+def test_background_prep_full_size_and_counter_sampler(ofdg, oracle, prep):
     """512x384 with 1024x768 pool images; ref-sampler blueprints bit-exact, then the device counter sampler
     (device cosf/sinf in the preparation record: <= 1 LSB on a small fraction of the pixels)."""
     W, H = 512, 384
-    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1, sampler=1, seed=21, num_objects=8)
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=prep, sampler=1, seed=21, num_objects=8)
     g = ofdg.Generator(p)
     g.pool_synthetic(3, 1024, 768, 4)
     host_pool = g.pool_download_all()
     q = params_for_oracle(oracle, p)
-    q.background_prep = 1
+    q.background_prep = prep
     tasks, bps, n = oracle.Sampler(5, W, H, 8).next(2)
     got = render_gpu(ofdg, g, tasks, 2, bps, n)
     e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
@@ -552,7 +588,7 @@ def test_background_prep_full_size_and_counter_sampler(ofdg, oracle):
 # ---- pool images smaller than the texture they feed (the resize branch of getRandomizedCrop, DG:102-106) ----
 @pytest.mark.parametrize("pool", [(3, 200, 150), (3, 97, 61), (3, 301, 150), (2, 255, 193)],
                          ids=["fg-crop_bg-enlarged", "fg-and-bg-enlarged", "bg-x-shrunk-y-enlarged", "odd-sizes-one-px-short"])
-@pytest.mark.parametrize("prep", [0, 1])
+@pytest.mark.parametrize("prep", [0, 1, 2])
 def test_small_pool_images_are_resized_like_the_reference(ofdg, oracle, pool, prep):
     """W x H = 128 x 96.  Images at least W x H give the foreground its centre crop, smaller ones are resized
     (CImg get_resize: linear when enlarging, moving average when shrinking, per axis, u8 between the passes);

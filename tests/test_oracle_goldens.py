@@ -176,9 +176,10 @@ def test_aa_byte_table(oracle):
     assert all(aa[c] == c - 1 for c in range(1, 255))
 
 
-def test_background_prep_identity_is_the_centre_crop(oracle):
+@pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
+def test_background_prep_identity_is_the_centre_crop(oracle, prep):
     """getRandomizedCrop(2W, 2H, angle 0, zoom 1, shift 0) is the centre 2W x 2H crop:
-    the restated preparation chain must reproduce the parity boundary exactly, and differ otherwise."""
+    the restated preparation chain (both forms) must reproduce the parity boundary exactly, and differ otherwise."""
     import numpy as np
     W, H, mode = 64, 48, 5
     rng = np.random.default_rng(3)
@@ -186,7 +187,7 @@ def test_background_prep_identity_is_the_centre_crop(oracle):
     tasks, bps, n = oracle.Sampler(mode, W, H, 3).next(2)
     p0 = oracle.default_params(W, H, mode, num_objects=3)
     p1 = oracle.default_params(W, H, mode, num_objects=3)
-    p1.background_prep = 1
+    p1.background_prep = prep
     base = oracle.render(p0, tasks, 2, bps, n, pool)
     changed = oracle.render(p1, tasks, 2, bps, n, pool)
     assert (base[0] != changed[0]).mean() > 0.2

@@ -34,6 +34,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# launch configuration of the product (README): eight HIP hardware queues, so that the context's four in-order chains
+# each own one (must be in the environment before the HIP runtime starts, i.e. before torch touches the GPU)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # BASELINE.json configs.  pool = (n, w, h); batch = samples per GPU and step.
 CONFIGS = {
@@ -257,6 +260,7 @@ def main():
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
             "config": {"workload": cfg["name"], "baseline_config": args.config, "batch_per_gpu": BATCH,
                        "background_prep": bool(args.background_prep), "startup": startup, "output_buffer_sets": NBUF,
+                       "chains": gen.num_chains(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
                                    if counter else "ref (host mt19937 streams) inside the timed region" if cfg["sampler"] == "ref" else
                                    "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},

@@ -1298,6 +1298,23 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
+// ... and the loads through it name the GLOBAL address space (a pointer rebuilt from integers is generic: flat_load with a
+// 64-bit address per lane; as global memory it is global_load v, voffset32, s[base])
+#ifndef OFDG_X_FLAT
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const u32x2_t g_uint2;
+typedef __attribute__((address_space(1))) const uint32_t g_uint32;
+typedef __attribute__((address_space(1))) const char g_char;
+__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) {
+  asm("" : "+v"(off));  // (the offset stays a 32-bit VGPR: a select folded into a 64-bit phi would defeat the saddr form)
+  const u32x2_t v = *(g_uint2*)((g_char*)base + off);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *(g_uint32*)((g_char*)base + off); }
+#else
+__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) { return *reinterpret_cast<const uint2*>(base + off); }
+__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *reinterpret_cast<const uint32_t*>(base + off); }
+#endif
 struct Taps4 {
   uint2 t0[kPx], t1[kPx];  // texel pairs of the two rows (mode 2: t0[p].x = the finished pixel)
   uint32_t xf, yf;         // fractions, byte p = pixel p
@@ -1328,8 +1345,8 @@ __device__ __forceinline__ Taps4 taps_issue(const uint32_t* __restrict__ tex_, c
 #pragma unroll
     for (int p = 0; p < kPx; ++p) {
       const uint32_t off = need ? ((uint32_t)(yh[p] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[p] >> 8)) * 4u : 0u;
-      T.t0[p] = *reinterpret_cast<const uint2*>(base + off);
-      T.t1[p] = *reinterpret_cast<const uint2*>(base1 + off);
+      T.t0[p] = gload2(base, off);
+      T.t1[p] = gload2(base1, off);
     }
   } else {
     const int tw2 = g.tw2, th2 = g.th2;
@@ -1350,8 +1367,8 @@ __device__ __forceinline__ Taps4 taps_issue(const uint32_t* __restrict__ tex_, c
         const uint32_t xa = (uint32_t)reflect(xl, g.tw, tw2), xb = (uint32_t)reflect(xl + 1, g.tw, tw2);
         const uint32_t ra = (uint32_t)reflect(yl, g.th, th2) * (uint32_t)g.pitch, rb = (uint32_t)reflect(yl + 1, g.th, th2) * (uint32_t)g.pitch;
         const char* base = reinterpret_cast<const char*>(tex);
-        T.t0[p] = make_uint2(*reinterpret_cast<const uint32_t*>(base + (ra + xa) * 4u), *reinterpret_cast<const uint32_t*>(base + (ra + xb) * 4u));
-        T.t1[p] = make_uint2(*reinterpret_cast<const uint32_t*>(base + (rb + xa) * 4u), *reinterpret_cast<const uint32_t*>(base + (rb + xb) * 4u));
+        T.t0[p] = make_uint2(gload1(base, (ra + xa) * 4u), gload1(base, (ra + xb) * 4u));
+        T.t1[p] = make_uint2(gload1(base, (rb + xa) * 4u), gload1(base, (rb + xb) * 4u));
         __builtin_amdgcn_sched_barrier(0);  // one pixel's addresses at a time: this (rare) path must not set the kernel's register count
       }
     } else {
@@ -1421,14 +1438,24 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   const int y = ty0 + sub * 4 + (lane >> 4);
   const bool inside = (x0 < W) && (y < H);
 
-  // ---- scalar stage 1: sample (+ background) record, block masks ----
-  const DevSample smp = samples[s];
+  // ---- scalar stage 1: sample (+ background) record and block masks, requested in ONE batch ----
+  // (the compiler loads a struct field where its first use is; an empty asm statement that names every value right here
+  //  makes that one place: one s_waitcnt for the whole record instead of one per use site)
+  struct SmpRec { int first_object, first_shape; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; } smp;
   unsigned long long mask0, mask1;
   {
+    const DevSample& R = samples[s];
+    smp.first_object = R.first_object; smp.first_shape = R.first_shape;
+    smp.bg_motion = R.bg_motion; smp.bg_tex_inv = R.bg_tex_inv; smp.bg_tex_base = R.bg_tex_base;
     const int nby = (H + kBandRows - 1) / kBandRows;
     const int brow = (ty0 + (sub >> 1) * kBandRows) / kBandRows;
     const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(blockmask + ((size_t)(s * nby + min(brow, nby - 1)) * tiles_x + tx0 / kTileW) * 2);
     mask0 = mm.x; mask1 = mm.y;
+    asm volatile("" : "+s"(smp.first_object), "+s"(smp.first_shape), "+s"(smp.bg_tex_base), "+s"(mask0), "+s"(mask1),
+                      "+s"(smp.bg_tex_inv.sx), "+s"(smp.bg_tex_inv.shy), "+s"(smp.bg_tex_inv.shx), "+s"(smp.bg_tex_inv.sy),
+                      "+s"(smp.bg_tex_inv.tx), "+s"(smp.bg_tex_inv.ty));
+    asm volatile("" : "+s"(smp.bg_motion.sx), "+s"(smp.bg_motion.shy), "+s"(smp.bg_motion.shx), "+s"(smp.bg_motion.sy),
+                      "+s"(smp.bg_motion.tx), "+s"(smp.bg_motion.ty));
   }
   unsigned long long omask = mask0 | mask1;
   const DevObject* objs = objects + smp.first_object;
@@ -1453,7 +1480,9 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
     }
   }
 
-  // ---- vector stage 1: background texels, coverage + records of the first kPre objects ----
+  // ---- vector stage 1: EVERY load the wave knows how to address goes out before anything is waited for: background
+  // taps of frame 1, background texels of frame 0, coverage + records of the first kPre objects.  Lanes outside the frame
+  // (W, H not multiples of the strip) read the texel at the origin instead of branching around the loads. ----
   WarpGeom gb;
   gb.tw = 2 * W; gb.th = 2 * H; gb.tw2 = 4 * W; gb.th2 = 4 * H;
   gb.mx2 = ((gb.tw2 & (gb.tw2 - 1)) == 0) ? gb.tw2 - 1 : -1;
@@ -1465,13 +1494,15 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   uint4 bq = make_uint4(0, 0, 0, 0);
   RowDDA Rb;
   Taps4 Tb;
-  if (inside) {
-    bq = *reinterpret_cast<const uint4*>(btex + (uint32_t)(yy * gb.pitch + xx));  // frame 0: identity warp == copy (DG:667-668, 680)
-    Rb = make_row<kPow2>(smp.bg_tex_inv, yy, gb.tw, gb.nshift);
-  } else {
-    Rb = RowDDA{0, 0, 1, 0, 0, 1};
-  }
+  Rb = make_row<kPow2>(smp.bg_tex_inv, inside ? yy : H / 2, gb.tw, gb.nshift);
   if constexpr (kPow2) Tb = taps_issue(btex, gb, Rb, xx, inside);
+  {
+    uint32_t boff = inside ? (uint32_t)(yy * gb.pitch + xx) * 4u : 0u;
+    asm("" : "+v"(boff));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = *(__attribute__((address_space(1))) const u32x4_t*)((g_char*)reinterpret_cast<const char*>(btex) + boff);  // frame 0: identity warp == copy (DG:667-668, 680)
+    bq = make_uint4(v.x, v.y, v.z, v.w);
+  }
   uint32_t pre_c0[kPre], pre_c1[kPre], pre_rec[kPre];
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
@@ -1694,7 +1725,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
 #ifndef OFDG_X_WAVES
 #define OFDG_X_ATTR
 #else
-#define OFDG_X_ATTR __attribute__((amdgpu_num_vgpr(OFDG_X_WAVES)))
+#define OFDG_X_ATTR __attribute__((amdgpu_waves_per_eu(OFDG_X_WAVES, OFDG_X_WAVES)))
 #endif
 // Leading scalar parameters are preloaded into SGPRs (no load, no wait before the first record fetch).
 __global__ __launch_bounds__(64) void compose_rigid_kernel(
@@ -1873,6 +1904,7 @@ __device__ __forceinline__ uint32_t lattice(uint32_t seed, uint32_t tex, uint32_
 // restated as one resampling; parity unpinned).  Strict fp32, same operation order as the oracle.
 __device__ __forceinline__ float cimg_modf(float x, float m) { return (float)((double)x - (double)m * floor((double)x / (double)m)); }
 __device__ __forceinline__ int mirror_index(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;  // (in range: no division)
   int m = i % (2 * n);
   if (m < 0) m += 2 * n;
   return m < n ? m : 2 * n - m - 1;
@@ -1985,13 +2017,15 @@ __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __
   const DevBgPlan q = plan[s];
   if (!q.ok) return;
   const int rw_ = q.cx1 - q.cx0 + 1, rh_ = q.my1 - q.my0 + 1;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= rw_ * rh_) return;
-  const int j = q.my0 + k / rw_, i = q.cx0 + k % rw_;
   const DevBgPrep p = prep[s];
-  const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
-  const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-  C[(size_t)s * cap_cw * cap_ch + (size_t)j * p.cw + i] = bgprep_rot_sample(p, pool + p.image_base, pw, ph, xc, yc);
+  uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {  // (the region's size is only known on the device)
+    const int jj = k / rw_;
+    const int j = q.my0 + jj, i = q.cx0 + (k - jj * rw_);
+    const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+    const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+    Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, pool + p.image_base, pw, ph, xc, yc);
+  }
 }
 // one axis of CImg's linear get_resize on BGRX texels (see pool_resize_axis_kernel): kAlongX: C (cw x ch) -> M (2W x ch);
 // else M -> B (2W x 2H), the sample's texture
@@ -2007,43 +2041,44 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
   // destination region
   const int dx0 = p.rx0, dx1 = p.rx1, dy0 = kAlongX ? q.my0 : p.ry0, dy1 = kAlongX ? q.my1 : p.ry1;
   const int rw_ = dx1 - dx0 + 1, rh_ = dy1 - dy0 + 1;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= rw_ * rh_) return;
-  const int y = dy0 + k / rw_, x = dx0 + k % rw_;
   const int n = kAlongX ? p.cw : p.ch, sdim = kAlongX ? TW : TH;  // source / destination length along the axis
   const int sw = kAlongX ? p.cw : TW;                                 // source row pitch
   const uint32_t* src = src_all + (kAlongX ? (size_t)s * cap_cw * cap_ch : (size_t)s * TW * cap_ch);
   uint32_t* dst = dst_all + (kAlongX ? (size_t)s * TW * cap_ch : (size_t)s * TW * TH);
-  const int kk = kAlongX ? x : y, line = kAlongX ? y : x;
-  auto texel = [&](int j) { return kAlongX ? src[(size_t)line * sw + j] : src[(size_t)j * sw + line]; };
   const int* tab = at + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
   const double* al_tab = alpha + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
-  uint32_t out = 0;
-  if (sdim == n) {
-    out = texel(kk);
-  } else if (sdim > n) {
-    const int a0 = tab[kk];
-    const double al = al_tab[kk];
-    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {
+    const int yy = k / rw_;
+    const int y = dy0 + yy, x = dx0 + (k - yy * rw_);
+    const int kk = kAlongX ? x : y, line = kAlongX ? y : x;
+    auto texel = [&](int j) { return kAlongX ? src[(size_t)line * sw + j] : src[(size_t)j * sw + line]; };
+    uint32_t out = 0;
+    if (sdim == n) {
+      out = texel(kk);
+    } else if (sdim > n) {
+      const int a0 = tab[kk];
+      const double al = al_tab[kk];
+      const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
-      out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+      for (int c = 0; c < 3; ++c) {
+        const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
+        out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+      }
+    } else {
+      float acc[3] = {0.f, 0.f, 0.f};
+      const int lo = kk * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
+      for (int j = lo / sdim; j * sdim < hi; ++j) {
+        const int a = j * sdim, b = a + sdim;
+        const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
+        const uint32_t t = texel(j);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
     }
-  } else {
-    float acc[3] = {0.f, 0.f, 0.f};
-    const long long lo = (long long)kk * n, hi = lo + n;
-    for (int j = (int)(lo / sdim); (long long)j * sdim < hi; ++j) {
-      const long long a = (long long)j * sdim, b = a + sdim;
-      const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
-      const uint32_t t = texel(j);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
+    dst[(size_t)y * TW + x] = out;
   }
-  dst[(size_t)y * TW + x] = out;
 }
 
 // one thread = 4 consecutive texels of a row of sample blockIdx.y's texture; texels outside the

@@ -267,6 +267,10 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     return OFDG_EHIP;
   }
   if (const char* v = std::getenv("OFDG_OVERLAP")) c->overlap = std::atoi(v) != 0;  // 0: everything on the caller's stream
+  // One hardware queue per chain: HIP maps its streams onto GPU_MAX_HW_QUEUES (default 4) queues.  A process started
+  // with GPU_MAX_HW_QUEUES >= 8 gets four chains (+5-8 % throughput, profiles/r02_chains_vs_hw_queues.txt); four chains
+  // on four queues share a queue with the caller's streams and are slower than three.
+  if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) c->n_chains = std::atoi(q) >= 8 ? 4 : 3;
   if (const char* v = std::getenv("OFDG_CHAINS")) c->n_chains = std::min(std::max(std::atoi(v), 1), (int)ofdg_ctx::kMaxChains);
   for (int i = 0; i < c->n_chains; ++i) {
     ofdg_ctx::Chain& ch = c->chains[i];
@@ -871,6 +875,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   int cap_cw = (int)((float)TW / 0.75f) + 2, cap_ch = (int)((float)TH / 0.75f) + 2;
   if (c->pool_w < TW || c->pool_h < TH) { cap_cw = c->pool_w + c->pool_h / 8 + 4; cap_ch = c->pool_h + c->pool_w / 8 + 4; }
   const bool staged = c->prm.background_prep == 1;
+  constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
   if (staged) {
     HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
     HIP_OK(c, sl.d_bgM.reserve((size_t)n * TW * cap_ch));
@@ -890,11 +895,11 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   }
   hipLaunchKernelGGL(bgprep_plan_kernel, dim3(n), dim3(64), 0, s, sl.d_bgprep.p, W, H, cap_cw, cap_ch, sl.d_bg_at.p, sl.d_bg_alpha.p,
                      sl.d_bgplan.p, c->d_err);
-  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3((cap_cw * cap_ch + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, c->pool,
+  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, c->pool,
                      c->pool_w, c->pool_h, cap_cw, cap_ch, sl.d_bgC.p);
-  hipLaunchKernelGGL(bgprep_resize_kernel<true>, dim3((TW * cap_ch + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
+  hipLaunchKernelGGL(bgprep_resize_kernel<true>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
                      sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgC.p, sl.d_bgM.p);
-  hipLaunchKernelGGL(bgprep_resize_kernel<false>, dim3((TW * TH + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
+  hipLaunchKernelGGL(bgprep_resize_kernel<false>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
                      sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgM.p, sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
   return OFDG_OK;

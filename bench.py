@@ -156,11 +156,11 @@ def main():
             if rank == 0:
                 gen = ofdg.Generator(prm)
                 gen.pool_synthetic(*cfg["pool"], POOL_SEED)
-            setup, _table = comm.bcast_setup(gen)
+            setup, table = comm.bcast_setup(gen)
             if rank != 0:
                 prm = comm.params_of(setup)
                 gen = ofdg.Generator(prm)
-                gen.pool_from_setup(setup)
+                gen.pool_from_setup(setup, table)
             comm.close()
             startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
         except Exception as e:  # (a start-up problem must not cost the measurement: same header over torch.distributed)

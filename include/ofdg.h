@@ -145,7 +145,8 @@ int ofdg_pool_alloc(ofdg_ctx* ctx, int n, int w, int h);
 int ofdg_pool_upload(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, int w, int h);
 /* A pool of n images of DIFFERENT sizes (real texture lists, TextureCollection DG:117-149): every image is
  * reduced at upload to what the path reads - its W x H foreground texture and its 2W x 2H background texture
- * (centre crop, or the CImg-resized whole image if it is smaller, DG:96-106).  Not with background_prep. */
+ * (centre crop, or the CImg-resized whole image if it is smaller, DG:96-106); with background_prep the whole
+ * image stays resident as well (the preparation works on the original image). */
 int ofdg_pool_alloc_mixed(ofdg_ctx* ctx, int n);
 int ofdg_pool_upload_mixed(ofdg_ctx* ctx, int index, const uint8_t* bgr_planar, int w, int h);
 /* Download texture `index` as planar B,G,R u8 (w*h*3 bytes). */
@@ -367,11 +368,14 @@ int ofdg_comm_bcast_pool(ofdg_comm* comm, int root, ofdg_ctx* ctx);
  * receiving rank creates its context with (rank, world_size and device come from the communicator). */
 int ofdg_setup_of(const ofdg_ctx* ctx, ofdg_setup* setup, ofdg_tex_entry* table, int table_cap);
 int ofdg_setup_params(const ofdg_setup* setup, const ofdg_comm* comm, ofdg_params* params);
-/* Allocate (synthetic: also fill) this rank's pool as the setup describes it. */
-int ofdg_setup_alloc_pool(ofdg_ctx* ctx, const ofdg_setup* setup);
+/* Allocate (synthetic: also fill) this rank's pool as the setup describes it; a mixed pool takes its image sizes
+ * from the index table that came with the setup. */
+int ofdg_setup_alloc_pool(ofdg_ctx* ctx, const ofdg_setup* setup, const ofdg_tex_entry* table);
 /* The derived textures of a mixed pool as raw device memory: [n][H][W] foreground and [n][2H][2W] background. */
 int ofdg_pool_device_mixed(ofdg_ctx* ctx, void** fg, unsigned long long* fg_bytes, void** bg,
                            unsigned long long* bg_bytes);
+/* ... and, with background_prep, whole image `index` (w * h BGRX texels): getRandomizedCrop reads the original. */
+int ofdg_pool_device_image(ofdg_ctx* ctx, int index, void** ptr, unsigned long long* bytes);
 /* DataGenerationLayer on a communicator: every rank passes the same prototxt; rank 0's options and texture
  * collection win (one broadcast), rank / world_size / device come from the communicator, and Forward yields
  * this rank's shard of every global batch. */

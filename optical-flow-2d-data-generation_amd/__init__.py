@@ -95,7 +95,7 @@ EXPORTS = [
     "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_num_chains",
     "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
     "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_pool", "ofdg_setup_of", "ofdg_setup_params",
-    "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_layer_create_dist",
+    "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_pool_device_image", "ofdg_layer_create_dist",
 ]
 
 
@@ -187,7 +187,8 @@ def lib():
         L.ofdg_comm_bcast_pool.argtypes = [vp, i32, vp]
         L.ofdg_setup_of.argtypes = [vp, C.POINTER(Setup), vp, i32]
         L.ofdg_setup_params.argtypes = [C.POINTER(Setup), vp, C.POINTER(Params)]
-        L.ofdg_setup_alloc_pool.argtypes = [vp, C.POINTER(Setup)]
+        L.ofdg_setup_alloc_pool.argtypes = [vp, C.POINTER(Setup), vp]
+        L.ofdg_pool_device_image.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_ulonglong)]
         L.ofdg_pool_device_mixed.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(C.c_ulonglong)]
         L.ofdg_layer_create_dist.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
         _lib = L
@@ -235,9 +236,9 @@ class Generator:
     def pool_alloc(self, n, w, h):
         self._check(lib().ofdg_pool_alloc(self.h, n, w, h))
 
-    def pool_from_setup(self, setup):
+    def pool_from_setup(self, setup, table=None):
         """Allocate (synthetic: also fill) the pool a broadcast Setup describes (ofdg_setup_alloc_pool)."""
-        self._check(lib().ofdg_setup_alloc_pool(self.h, C.byref(setup)))
+        self._check(lib().ofdg_setup_alloc_pool(self.h, C.byref(setup), table))
 
     def pool_upload(self, index, bgr_planar):
         import numpy as np

@@ -201,6 +201,17 @@ int ofdg_comm_bcast_pool(ofdg_comm* c, int root, ofdg_ctx* ctx) {
   COMM_HIP(c, hipSetDevice(c->device));
   COMM_NCCL(c, R, R->Broadcast(ptr, ptr, (size_t)bytes, ncclUint8, root, c->comm, c->stream));
   if (ptr2) COMM_NCCL(c, R, R->Broadcast(ptr2, ptr2, (size_t)bytes2, ncclUint8, root, c->comm, c->stream));
+  if (ptr2 && ofdg_ctx_params(ctx)->background_prep) {  // mixed pool + background preparation: the whole images too
+    int n = 0;
+    ofdg_pool_info(ctx, &n, nullptr, nullptr);
+    for (int i = 0; i < n; ++i) {
+      void* ip = nullptr;
+      unsigned long long ib = 0;
+      rc = ofdg_pool_device_image(ctx, i, &ip, &ib);
+      if (rc != OFDG_OK) { c->err = std::string("ofdg_pool_device_image: ") + ofdg_last_error(ctx); return rc; }
+      COMM_NCCL(c, R, R->Broadcast(ip, ip, (size_t)ib, ncclUint8, root, c->comm, c->stream));
+    }
+  }
   COMM_HIP(c, hipStreamSynchronize(c->stream));
   return OFDG_OK;
 }

@@ -840,7 +840,8 @@ __device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const 
 // Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799,
 // computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
 // CImg<float>::_linear_atXY (Neumann): clamp, nx = dx > 0 ? x+1 : x, fp32 polynomial.
-__device__ __forceinline__ float linear_neumann(const float* __restrict__ img, int w, int h, float fx, float fy) {
+template <class Ptr>
+__device__ __forceinline__ float linear_neumann(Ptr img, int w, int h, float fx, float fy) {
   const float nfx = fx <= 0 ? 0 : (fx >= (float)(w - 1) ? (float)(w - 1) : fx);
   const float nfy = fy <= 0 ? 0 : (fy >= (float)(h - 1) ? (float)(h - 1) : fy);
   const unsigned x = (unsigned)nfx, y = (unsigned)nfy;
@@ -1911,7 +1912,9 @@ __device__ __forceinline__ int mirror_index(int i, int n) {
 }
 // R(x, y) of CImg's rotate(angle, 1, 3) for xc = x - rw2, yc = y - rh2, on the SHIFTED pool image (strict fp32, the
 // oracle's operation order): mirrored float coordinates, _linear_atXY (Neumann), truncation to u8 per channel
-__device__ __forceinline__ uint32_t bgprep_rot_sample(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, float xc, float yc) {
+__device__ __forceinline__ uint32_t bgprep_rot_sample(const DevBgPrep& p, float xc, float yc) {
+  OFDG_GLOBAL const uint32_t* img = (OFDG_GLOBAL const uint32_t*)p.image_addr;
+  const int pw = p.pw, ph = p.ph;
   const float ww = 2.0f * pw, hh = 2.0f * ph;
   float mx = __fadd_rn(__fadd_rn(p.w2, __fmul_rn(xc, p.ca)), __fmul_rn(yc, p.sa));
   float my = __fadd_rn(__fsub_rn(p.h2, __fmul_rn(xc, p.sa)), __fmul_rn(yc, p.ca));
@@ -1946,10 +1949,10 @@ __device__ __forceinline__ uint32_t bgprep_rot_sample(const DevBgPrep& p, const 
   return out;
 }
 // background_prep = 2 (fast form): one prepared texel by ONE resampling along the composed coordinate map
-__device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, const uint32_t* __restrict__ img, int pw, int ph, int u, int v) {
+__device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, int u, int v) {
   const float cxf = fminf((float)(p.cw - 1), __fmul_rn((float)u, p.fx)), cyf = fminf((float)(p.ch - 1), __fmul_rn((float)v, p.fy));
   const float xc = __fsub_rn(__fadd_rn((float)p.x0, cxf), p.rw2), yc = __fsub_rn(__fadd_rn((float)p.y0, cyf), p.rh2);
-  return bgprep_rot_sample(p, img, pw, ph, xc, yc);
+  return bgprep_rot_sample(p, xc, yc);
 }
 
 // ---- background_prep = 1: the CImg chain stage by stage (DG:96-103), four u8 images -------------------------------
@@ -2011,8 +2014,7 @@ __global__ __launch_bounds__(64) void bgprep_plan_kernel(const DevBgPrep* __rest
 }
 // C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y
 __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, const DevBgPlan* __restrict__ plan,
-                                                             const uint32_t* __restrict__ pool, int pw, int ph, int cap_cw, int cap_ch,
-                                                             uint32_t* __restrict__ C) {
+                                                             int cap_cw, int cap_ch, uint32_t* __restrict__ C) {
   const int s = blockIdx.y;
   const DevBgPlan q = plan[s];
   if (!q.ok) return;
@@ -2024,7 +2026,7 @@ __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __
     const int j = q.my0 + jj, i = q.cx0 + (k - jj * rw_);
     const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
     const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-    Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, pool + p.image_base, pw, ph, xc, yc);
+    Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, xc, yc);
   }
 }
 // one axis of CImg's linear get_resize on BGRX texels (see pool_resize_axis_kernel): kAlongX: C (cw x ch) -> M (2W x ch);
@@ -2083,8 +2085,7 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 
 // one thread = 4 consecutive texels of a row of sample blockIdx.y's texture; texels outside the
 // sample's read region (DevBgPrep.r*) are skipped - compose never looks at them
-__global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, const uint32_t* __restrict__ pool,
-                                                     int pw, int ph, int W, int H, uint32_t* __restrict__ bgtex) {
+__global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict__ prep, int W, int H, uint32_t* __restrict__ bgtex) {
   const int TW = 2 * W, TH = 2 * H, quads = TW / 4;
   const int s = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2092,12 +2093,11 @@ __global__ __launch_bounds__(256) void bgprep_kernel(const DevBgPrep* __restrict
   const int v = i / quads, u0 = (i - v * quads) * 4;
   const DevBgPrep p = prep[s];
   if (v < p.ry0 || v > p.ry1 || u0 + 3 < p.rx0 || u0 > p.rx1) return;
-  const uint32_t* img = pool + p.image_base;
   uint4 o;
-  o.x = bgprep_texel(p, img, pw, ph, u0, v);
-  o.y = bgprep_texel(p, img, pw, ph, u0 + 1, v);
-  o.z = bgprep_texel(p, img, pw, ph, u0 + 2, v);
-  o.w = bgprep_texel(p, img, pw, ph, u0 + 3, v);
+  o.x = bgprep_texel(p, u0, v);
+  o.y = bgprep_texel(p, u0 + 1, v);
+  o.z = bgprep_texel(p, u0 + 2, v);
+  o.w = bgprep_texel(p, u0 + 3, v);
   *reinterpret_cast<uint4*>(bgtex + (size_t)s * TW * TH + (size_t)v * TW + u0) = o;
 }
 

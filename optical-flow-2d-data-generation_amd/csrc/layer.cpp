@@ -159,6 +159,9 @@ void parse_message(Lexer& lx, const std::string& scope, LayerConfig* cfg, bool t
 LayerConfig parse_layer_prototxt(const std::string& text) {
   LayerConfig cfg;
   ofdg_default_params(&cfg.params);
+  // the reference always runs getRandomizedCrop(2W, 2H, rot, zoom, shift) on the background (DataGenerator.cpp:1186-1192):
+  // the layer does too unless the prototxt says `background_prep: false` (extension key)
+  cfg.params.background_prep = 1;
   Lexer lx(text);
   parse_message(lx, "", &cfg, true);
   return cfg;
@@ -237,8 +240,6 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
     }
     if (i == 0) { pw = w; ph = h; } else if (w != pw || h != ph) mixed = true;
   }
-  const ofdg_params* prm = ofdg_ctx_params(ctx);
-  if (mixed && prm && prm->background_prep) throw std::runtime_error("Could not open texture collection (background_prep needs pool images of one size)");
   const int rc_alloc = mixed ? ofdg_pool_alloc_mixed(ctx, (int)paths.size()) : ofdg_pool_alloc(ctx, (int)paths.size(), pw, ph);
   if (rc_alloc != OFDG_OK) throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
   for (size_t i = 0; i < paths.size(); ++i) {
@@ -292,7 +293,7 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg
       p.first_level_threads = cfg_.params.first_level_threads; p.second_level_threads = cfg_.params.second_level_threads;
       cfg_.params = p;
       create();
-      if (ofdg_setup_alloc_pool(ctx_, &su) != OFDG_OK)
+      if (ofdg_setup_alloc_pool(ctx_, &su, table.data()) != OFDG_OK)
         throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx_));
     }
     // a texture collection read from disk lives on rank 0 only until here: replicate it over xGMI

@@ -55,6 +55,10 @@ struct ofdg_ctx {
   bool pool_final = false;       // derived pools match the current pool contents
   bool pool_mixed = false;       // ofdg_pool_alloc_mixed: only the derived pools exist (images of different sizes)
   std::vector<std::pair<int, int>> mixed_sizes;  // source image sizes of a mixed pool (index table)
+  // background_prep on a mixed pool: the whole images stay resident (getRandomizedCrop works on the original image)
+  std::vector<uint32_t*> mixed_images;
+  std::vector<DevTexEntry> tex_table;   // host copy of ...
+  DevTexEntry* d_tex_table = nullptr;   // ... the per-image table the device sampler reads
   int pool_kind = OFDG_POOL_UNIFORM;
   uint32_t pool_seed = 0;
   // sampler
@@ -303,6 +307,8 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (c->pool) (void)hipFree(c->pool);
   if (c->pool_fg) (void)hipFree(c->pool_fg);
   if (c->pool_bg) (void)hipFree(c->pool_bg);
+  for (uint32_t* im : c->mixed_images) if (im) (void)hipFree(im);
+  if (c->d_tex_table) (void)hipFree(c->d_tex_table);
   auto drop_slot = [](ofdg_ctx::Slot& sl) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
@@ -368,9 +374,12 @@ int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
 int ofdg_pool_alloc_mixed(ofdg_ctx* c, int n) {
   if (!c) return OFDG_EINVAL;
   if (n < 1) { c->err = "texture pool needs at least one image"; return OFDG_ETEXTURES; }
-  if (c->prm.background_prep) { c->err = "background_prep needs a pool of whole images of one size (ofdg_pool_alloc)"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;
   HIP_OK(c, hipDeviceSynchronize());
+  for (uint32_t* im : c->mixed_images) if (im) (void)hipFree(im);
+  c->mixed_images.assign((size_t)n, nullptr);
+  if (c->d_tex_table) { (void)hipFree(c->d_tex_table); c->d_tex_table = nullptr; }
+  c->tex_table.clear();
   if (c->pool) { HIP_OK(c, hipFree(c->pool)); c->pool = nullptr; }
   if (c->pool_fg) { HIP_OK(c, hipFree(c->pool_fg)); c->pool_fg = nullptr; }
   if (c->pool_bg) { HIP_OK(c, hipFree(c->pool_bg)); c->pool_bg = nullptr; }
@@ -410,7 +419,14 @@ int ofdg_pool_upload_mixed(ofdg_ctx* c, int index, const uint8_t* bgr_planar, in
   int rc = texture_of_image(c, img, w, h, W, H, c->pool_fg + (size_t)index * W * H);
   if (rc == OFDG_OK) rc = texture_of_image(c, img, w, h, 2 * W, 2 * H, c->pool_bg + (size_t)index * 4 * W * H);
   HIP_OK(c, hipDeviceSynchronize());
-  (void)hipFree(tmp); (void)hipFree(img);
+  (void)hipFree(tmp);
+  if (rc == OFDG_OK && c->prm.background_prep) {  // the background preparation reads the original image
+    if (c->mixed_images[(size_t)index]) (void)hipFree(c->mixed_images[(size_t)index]);
+    c->mixed_images[(size_t)index] = img;
+    if (c->d_tex_table) { (void)hipFree(c->d_tex_table); c->d_tex_table = nullptr; }
+  } else {
+    (void)hipFree(img);
+  }
   if (rc == OFDG_OK) c->mixed_sizes[(size_t)index] = std::make_pair(w, h);
   return rc;
 }
@@ -514,12 +530,33 @@ int ofdg_setup_of(const ofdg_ctx* c, ofdg_setup* su, ofdg_tex_entry* table, int 
   return OFDG_OK;
 }
 
-int ofdg_setup_alloc_pool(ofdg_ctx* c, const ofdg_setup* su) {
+int ofdg_setup_alloc_pool(ofdg_ctx* c, const ofdg_setup* su, const ofdg_tex_entry* table) {
   if (!c || !su) return OFDG_EINVAL;
   if (su->width != c->prm.width || su->height != c->prm.height) { c->err = "setup_alloc_pool: the context was not created from this setup"; return OFDG_EINVAL; }
   if (su->pool_kind == OFDG_POOL_SYNTHETIC) return ofdg_pool_synthetic(c, su->n_tex, su->pool_w, su->pool_h, su->pool_seed);
-  if (su->pool_kind == OFDG_POOL_MIXED) return ofdg_pool_alloc_mixed(c, su->n_tex);
-  return ofdg_pool_alloc(c, su->n_tex, su->pool_w, su->pool_h);
+  if (su->pool_kind != OFDG_POOL_MIXED) return ofdg_pool_alloc(c, su->n_tex, su->pool_w, su->pool_h);
+  int rc = ofdg_pool_alloc_mixed(c, su->n_tex);
+  if (rc != OFDG_OK) return rc;
+  if (!table || su->n_table < su->n_tex) { c->err = "setup_alloc_pool: a mixed pool needs the index table (image sizes)"; return OFDG_EINVAL; }
+  for (int i = 0; i < su->n_tex; ++i) {
+    c->mixed_sizes[(size_t)i] = std::make_pair((int)table[i].w, (int)table[i].h);
+    if (c->prm.background_prep)  // the whole images arrive with ofdg_comm_bcast_pool
+      HIP_OK(c, hipMalloc((void**)&c->mixed_images[(size_t)i], (size_t)table[i].w * table[i].h * sizeof(uint32_t)));
+  }
+  return OFDG_OK;
+}
+
+// image `index` of a mixed pool kept whole for the background preparation, as raw device memory (w * h BGRX texels)
+int ofdg_pool_device_image(ofdg_ctx* c, int index, void** ptr, unsigned long long* bytes) {
+  if (!c || !ptr || !bytes) return OFDG_EINVAL;
+  if (!c->pool_mixed || !c->prm.background_prep || index < 0 || index >= c->pool_n || !c->mixed_images[(size_t)index]) {
+    c->err = "pool_device_image: no whole image " + std::to_string(index) + " (mixed pool with background_prep only)";
+    return OFDG_ETEXTURES;
+  }
+  HIP_OK(c, hipDeviceSynchronize());
+  *ptr = (void*)c->mixed_images[(size_t)index];
+  *bytes = (unsigned long long)c->mixed_sizes[(size_t)index].first * c->mixed_sizes[(size_t)index].second * sizeof(uint32_t);
+  return OFDG_OK;
 }
 
 // ---- sampler ---------------------------------------------------------------------------
@@ -608,8 +645,8 @@ static int ensure_counter_croptab(ofdg_ctx* c) {
     hipLaunchKernelGGL(wf_resize2_kernel, dim3((2 * W * 2 * H + 255) / 256), dim3(256), 0, 0, src, W + 1, H + 1, 2 * W, 2 * H,
                        c->d_rs_xi, c->d_rs_xa, c->d_rs_yi, c->d_rs_ya, dst, c->d_cs_bgwarp_max + k);
     HIP_OK(c, hipGetLastError());
-    tab[k] = DevCropRef{src, c->d_warp_max + k, W + 1, H + 1};
-    tab[(size_t)n + k] = DevCropRef{dst, c->d_cs_bgwarp_max + k, 2 * W, 2 * H};
+    tab[k] = make_crop_ref(src, c->d_warp_max + k, W + 1, H + 1);
+    tab[(size_t)n + k] = make_crop_ref(dst, c->d_cs_bgwarp_max + k, 2 * W, 2 * H);
   }
   HIP_OK(c, hipMemcpy(c->d_cs_croptab, tab.data(), tab.size() * sizeof(DevCropRef), hipMemcpyHostToDevice));
   HIP_OK(c, hipDeviceSynchronize());
@@ -706,6 +743,30 @@ static int finalise_pool(ofdg_ctx* c) {
   return OFDG_OK;
 }
 
+// background_prep on a mixed pool: the per-image table (address, size) on the device, and the workspace the staged chain
+// needs for the largest crop of a rotated image
+static int ensure_tex_table(ofdg_ctx* c) {
+  if (!c->pool_mixed || !c->prm.background_prep || c->d_tex_table) return OFDG_OK;
+  c->tex_table.resize((size_t)c->pool_n);
+  for (int i = 0; i < c->pool_n; ++i) {
+    if (!c->mixed_images[(size_t)i]) { c->err = "background_prep: image " + std::to_string(i) + " of the mixed pool has not been uploaded"; return OFDG_ETEXTURES; }
+    c->tex_table[(size_t)i] = DevTexEntry{(uint64_t)(uintptr_t)c->mixed_images[(size_t)i], c->mixed_sizes[(size_t)i].first, c->mixed_sizes[(size_t)i].second};
+  }
+  HIP_OK(c, hipMalloc((void**)&c->d_tex_table, c->tex_table.size() * sizeof(DevTexEntry)));
+  HIP_OK(c, hipMemcpy(c->d_tex_table, c->tex_table.data(), c->tex_table.size() * sizeof(DevTexEntry), hipMemcpyHostToDevice));
+  return OFDG_OK;
+}
+static void bgprep_caps(const ofdg_ctx* c, int* cap_cw, int* cap_ch) {
+  const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
+  // crops of the rotated image up to zoom 0.75 (the sampler draws 0.8 .. 1.2) ...
+  int cw = (int)((float)TW / 0.75f) + 2, ch = (int)((float)TH / 0.75f) + 2;
+  // ... or the whole rotated image when a pool image is smaller than 2W x 2H (DG:102-106; rotation by up to +-3.2 "degrees")
+  auto small = [&](int w, int h) { if (w < TW || h < TH) { cw = std::max(cw, w + h / 8 + 4); ch = std::max(ch, h + w / 8 + 4); } };
+  if (c->pool_mixed) for (const auto& wh : c->mixed_sizes) small(wh.first, wh.second);
+  else small(c->pool_w, c->pool_h);
+  *cap_cw = cw; *cap_ch = ch;
+}
+
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
@@ -713,7 +774,8 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
-                  c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin};
+                  c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin,
+                  (unsigned long long)(uintptr_t)c->pool, c->d_tex_table};
   hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
                      sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
@@ -870,10 +932,8 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   const int W = c->prm.width, H = c->prm.height, TW = 2 * W, TH = 2 * H;
   HIP_OK(c, sl.d_bgprep.reserve(n));
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
-  // workspace of the staged chain: crops of the rotated image up to zoom 0.75 (the sampler draws 0.8 .. 1.2), or the whole
-  // rotated image when the pool images are smaller than 2W x 2H (DG:102-106; rotation by up to +-3.2 "degrees")
-  int cap_cw = (int)((float)TW / 0.75f) + 2, cap_ch = (int)((float)TH / 0.75f) + 2;
-  if (c->pool_w < TW || c->pool_h < TH) { cap_cw = c->pool_w + c->pool_h / 8 + 4; cap_ch = c->pool_h + c->pool_w / 8 + 4; }
+  int cap_cw, cap_ch;
+  bgprep_caps(c, &cap_cw, &cap_ch);
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
   if (staged) {
@@ -888,15 +948,14 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
     HIP_OK(c, hipStreamSynchronize(s));  // (pageable source owned by the caller's batch)
   }
   if (!staged) {
-    hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, c->pool, c->pool_w, c->pool_h, W, H,
-                       sl.d_bgtex.p);
+    hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, W, H, sl.d_bgtex.p);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
   hipLaunchKernelGGL(bgprep_plan_kernel, dim3(n), dim3(64), 0, s, sl.d_bgprep.p, W, H, cap_cw, cap_ch, sl.d_bg_at.p, sl.d_bg_alpha.p,
                      sl.d_bgplan.p, c->d_err);
-  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, c->pool,
-                     c->pool_w, c->pool_h, cap_cw, cap_ch, sl.d_bgC.p);
+  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, cap_cw, cap_ch,
+                     sl.d_bgC.p);
   hipLaunchKernelGGL(bgprep_resize_kernel<true>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
                      sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgC.p, sl.d_bgM.p);
   hipLaunchKernelGGL(bgprep_resize_kernel<false>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
@@ -910,7 +969,10 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
                        int n_bps, hipStream_t st, ofdg_ctx::Stage& stage) {
   if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
+  { int rct = ensure_tex_table(c); if (rct != OFDG_OK) return rct; }
   RealizeConfig cfg{c->prm.width, c->prm.height, c->prm.mode, c->pool_n, c->pool_w, c->pool_h, c->prm.background_prep};
+  cfg.pool_addr = (uint64_t)(uintptr_t)c->pool;
+  cfg.tex_table = c->pool_mixed && c->prm.background_prep ? c->tex_table.data() : nullptr;
   cfg.fg_stride = c->fg_src.stride; cfg.fg_origin = c->fg_src.origin; cfg.bg_stride = c->bg_src.stride; cfg.bg_origin = c->bg_src.origin;
   // the previous copies out of this staging buffer must have left it
   if (stage.pending) { HIP_OK(c, hipEventSynchronize(stage.free_ev)); stage.pending = false; }
@@ -983,10 +1045,10 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
         hipLaunchKernelGGL(wf_resize2_kernel, dim3((2 * W * 2 * H + 255) / 256), dim3(256), 0, st, src, W + 1, H + 1, 2 * W, 2 * H,
                            c->d_rs_xi, c->d_rs_xa, c->d_rs_yi, c->d_rs_ya, dst, sl.d_bgwarp_max.p + bg_at);
         HIP_OK(c, hipGetLastError());
-        tab[k] = DevCropRef{dst, sl.d_bgwarp_max.p + bg_at, 2 * W, 2 * H};
+        tab[k] = make_crop_ref(dst, sl.d_bgwarp_max.p + bg_at, 2 * W, 2 * H);
         ++bg_at;
       } else {
-        tab[k] = DevCropRef{src, c->d_warp_max + B.crops[k].crop, W + 1, H + 1};
+        tab[k] = make_crop_ref(src, c->d_warp_max + B.crops[k].crop, W + 1, H + 1);
       }
     }
     // small table: a synchronous copy from pageable memory is fine here (upload path)
@@ -1051,6 +1113,7 @@ int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flo
 static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   if (c->prm.mode == 9) { int rcw = ensure_counter_croptab(c); if (rcw != OFDG_OK) return rcw; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
+  { int rct = ensure_tex_table(c); if (rct != OFDG_OK) return rct; }
   if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   if (n < 1 || n > 512) { c->err = "counter sampler: batch must be 1..512 samples"; return OFDG_EINVAL; }
   const int W = c->prm.width, H = c->prm.height;

@@ -103,9 +103,16 @@ struct DevBgPrep {
   int32_t x0, y0;          // crop origin in the rotated image
   int32_t cw, ch;          // crop size
   int32_t shx, shy;        // get_shift offsets
-  uint64_t image_base;     // texel offset of the pool image
+  uint64_t image_addr;     // device address of the pool image (BGRX texels, pw x ph)
   int32_t rx0, ry0, rx1, ry1;  // texels of the 2W x 2H texture compose can read (inclusive); the rest is not rendered
   int32_t rw, rh;              // size of the rotated image (crop coordinates are mirrored into it)
+  int32_t pw, ph;              // size of the pool image (texture lists may hold images of different sizes)
+};
+// Where a whole pool image lives (background preparation reads the original image): the table of a pool with images of
+// different sizes; a uniform pool needs none (image i = base + i * w * h).
+struct DevTexEntry {
+  uint64_t addr;
+  int32_t w, h;
 };
 
 // Where an object's texture lives relative to a pool pointer: image i starts at i * stride, its
@@ -117,12 +124,24 @@ struct TexSource {
   int32_t pitch, pad;
 };
 
+// Pointers the kernels read out of records are typed as GLOBAL memory in device code (a pointer loaded from memory is
+// generic otherwise: flat_load, which also counts on lgkmcnt and so serialises with every scalar wait).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OFDG_GLOBAL __attribute__((address_space(1)))
+#else
+#define OFDG_GLOBAL
+#endif
 // One served warp crop as the kernels see it (mode 9).
 struct DevCropRef {
-  const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
-  const unsigned* max_bits;  // float bits of max |iflow| over the crop (NaNs ignored)
+  OFDG_GLOBAL const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
+  OFDG_GLOBAL const unsigned* max_bits;  // float bits of max |iflow| over the crop (NaNs ignored)
   int32_t w, h;
 };
+inline DevCropRef make_crop_ref(const float* data, const unsigned* max_bits, int w, int h) {
+  DevCropRef r;
+  r.data = (OFDG_GLOBAL const float*)data; r.max_bits = (OFDG_GLOBAL const unsigned*)max_bits; r.w = w; r.h = h;
+  return r;
+}
 
 struct RenderDims {
   int32_t W, H;            // output size

@@ -29,7 +29,7 @@ Motion object_motion(const ofdg_blueprint& p, const Mat& bg_motion, int W, int H
 // CImg 2.x: rotate() takes degrees and grows the image to round(1 + |(w-1)cos| + |(h-1)sin|);
 // crop(x0, y0, x1, y1) with float -> int truncation of x1 = x0 + 2W/zoom - 1; linear
 // get_resize with boundary 0 steps (w - 1)/(sx - 1) when enlarging, w/sx otherwise.
-DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_base) {
+DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_addr) {
   DevBgPrep p;
   const int TW = 2 * W, TH = 2 * H;
   const float nangle = (float)(angle - 360.0f * std::floor((double)angle / 360.0f));
@@ -52,7 +52,8 @@ DevBgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, in
   p.fx = TW > p.cw ? (float)((p.cw - 1.0) / (TW - 1.0)) : (float)((double)p.cw / TW);
   p.fy = TH > p.ch ? (float)((p.ch - 1.0) / (TH - 1.0)) : (float)((double)p.ch / TH);
   p.shx = shift_x; p.shy = shift_y;
-  p.image_base = image_base;
+  p.image_addr = image_addr;
+  p.pw = pw; p.ph = ph;
   p.rx0 = 0; p.ry0 = 0; p.rx1 = TW - 1; p.ry1 = TH - 1;
   return p;
 }
@@ -163,8 +164,11 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       o.tex_inv = mat_invert(warp);
       if (cfg.background_prep) {
         // the sample's own prepared 2W x 2H texture (bgprep_kernel), in the slot's buffer
-        DevBgPrep bp = make_bg_prep(cfg.pool_w, cfg.pool_h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y,
-                                    (uint64_t)(pb.tex_id % cfg.pool_n) * img_texels);
+        const int ti = pb.tex_id % cfg.pool_n;
+        DevBgPrep bp = cfg.tex_table
+            ? make_bg_prep(cfg.tex_table[ti].w, cfg.tex_table[ti].h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y, cfg.tex_table[ti].addr)
+            : make_bg_prep(cfg.pool_w, cfg.pool_h, W, H, pb.tex_rot, pb.tex_scale, pb.tex_shift_x, pb.tex_shift_y,
+                           cfg.pool_addr + (uint64_t)ti * img_texels * sizeof(uint32_t));
         // (mode 9 re-samples the background through a warp field: anything may be read)
         if (!(mode9 && pb.do_warpfield_deformation)) bg_prep_region(o.tex_inv, W, H, &bp.rx0, &bp.ry0, &bp.rx1, &bp.ry1);
         out->bgprep.push_back(bp);

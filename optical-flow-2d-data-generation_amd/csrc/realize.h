@@ -75,10 +75,13 @@ struct RealizeConfig {
   int background_prep = 0;
   // texture sources (TexSource of the ctx); 0 stride = "centre crops of the pool images" computed from pool_w/h
   uint64_t fg_stride = 0, fg_origin = 0, bg_stride = 0, bg_origin = 0;
+  // background_prep: where the whole images are - a uniform pool at pool_addr, or one entry per image (mixed pool)
+  uint64_t pool_addr = 0;
+  const DevTexEntry* tex_table = nullptr;
 };
 
 // getRandomizedCrop(2W, 2H, angle, zoom, shift) of a pool image as one coordinate map (DG:87-109).
-DevBgPrep make_bg_prep(int pool_w, int pool_h, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_base);
+DevBgPrep make_bg_prep(int pool_w, int pool_h, int W, int H, float angle, float zoom, int shift_x, int shift_y, uint64_t image_addr);
 // The texels of the 2W x 2H background texture compose reads: the centre W x H window (frame 0)
 // and the window mapped through the texture warp `tex_inv` (frame 1, bilinear), with a margin;
 // the whole texture if that leaves it (reflection).

@@ -27,7 +27,7 @@ def test_bcast_setup_carries_stream_and_index_table(ofdg, comm):
     p = comm.params_of(su)
     assert (p.rank, p.world_size, p.device, p.mode, p.seed) == (0, 1, 0, 11, 77)
     g2 = ofdg.Generator(p)
-    g2.pool_from_setup(su)
+    g2.pool_from_setup(su, table)
     assert np.array_equal(g.pool_download_all(), g2.pool_download_all())
     a, b = ofdg.alloc_outputs(4, 96, 128), ofdg.alloc_outputs(4, 96, 128)
     g.forward(*a); g.synchronize()

@@ -337,7 +337,8 @@ layer {
 
 def test_layer_surface_forward_matches_oracle(ofdg, oracle, tmp_path):
     """The Caffe-layer-shaped host class: prototxt -> LayerSetUp -> Forward, with a texture
-    list file of binary PPMs; two consecutive Forward() calls continue the 45 streams."""
+    list file of binary PPMs; two consecutive Forward() calls continue the 45 streams.  The layer applies the
+    background preparation by default (`background_prep: false` switches it off)."""
     rng = np.random.RandomState(5)
     paths = []
     pool = []
@@ -355,6 +356,7 @@ def test_layer_surface_forward_matches_oracle(ofdg, oracle, tmp_path):
     assert layer.type() == "DataGeneration"
     s = oracle.Sampler(7, 128, 96)
     prm = oracle.default_params(128, 96, 7)
+    prm.background_prep = 1     # the layer prepares every background like the reference (DataGenerator.cpp:1186-1192)
     for _ in range(2):
         a, b, f = layer.Forward()
         assert tuple(a.shape) == (3, 3, 96, 128) and tuple(f.shape) == (3, 2, 96, 128)
@@ -609,24 +611,29 @@ def test_small_pool_images_are_resized_like_the_reference(ofdg, oracle, pool, pr
     assert ulp_diff(got[2], ef).max() == 0
 
 
-def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle):
+@pytest.mark.parametrize("prep", [0, 1, 2], ids=["centre-crop", "cimg-chain", "one-resampling"])
+def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle, prep):
     """ofdg_pool_alloc_mixed / ofdg_pool_upload_mixed (texture lists with images of different sizes): every image is
-    reduced at upload to its W x H and 2W x 2H textures.  A mixed pool holding ONE image renders exactly like the
-    uniform pool of that image (itself bit-exact against the oracle), for a large, a medium and a small image; and
-    a three-image mixed pool is consistent with them sample by sample when all of a sample's texture ids hit one image."""
+    reduced at upload to its W x H and 2W x 2H textures (with background_prep the whole image stays resident too, for
+    getRandomizedCrop on the original).  A mixed pool holding ONE image renders exactly like the uniform pool of that
+    image (itself bit-exact against the oracle), for a large, a medium and a small image; and a three-image mixed
+    pool is consistent with them sample by sample when all of a sample's texture ids hit one image - also through
+    the device counter sampler, which reads the per-image table."""
     W, H, B = 128, 96, 3
     rng = np.random.default_rng(11)
     images = [rng.integers(0, 256, size=(3, hh, ww), dtype=np.uint8) for ww, hh in ((301, 233), (200, 150), (90, 75))]
     # smooth them a little so that bilinear interpolation is not just noise
     images = [((im.astype(np.uint16) + np.roll(im, 1, axis=2) + np.roll(im, 1, axis=1) + np.roll(np.roll(im, 1, axis=1), 1, axis=2)) // 4).astype(np.uint8) for im in images]
     tasks, bps, n = oracle.Sampler(5, W, H).next(B)
-    prm = ofdg.default_params(width=W, height=H, mode=5)
+    prm = ofdg.default_params(width=W, height=H, mode=5, background_prep=prep)
+    q = params_for_oracle(oracle, prm)
+    q.background_prep = prep
     for im in images:
         gm = ofdg.Generator(prm)
         gm.pool_alloc_mixed(1)
         gm.pool_upload_mixed(0, im)
         got = render_gpu(ofdg, gm, tasks, B, bps, n)
-        e0, e1, ef = oracle.render(params_for_oracle(oracle, prm), tasks, B, bps, n, im[None])
+        e0, e1, ef = oracle.render(q, tasks, B, bps, n, im[None])
         assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1) and ulp_diff(got[2], ef).max() == 0
     g3 = ofdg.Generator(prm)
     g3.pool_alloc_mixed(3)
@@ -636,8 +643,27 @@ def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle):
         for i in range(n):
             bps[i].tex_id = k
         got = render_gpu(ofdg, g3, tasks, B, bps, n)
-        e0, e1, ef = oracle.render(params_for_oracle(oracle, prm), tasks, B, bps, n, im[None])
+        e0, e1, ef = oracle.render(q, tasks, B, bps, n, im[None])
         assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1)
+    # the device counter sampler reads the per-image table: a mixed pool holding the medium image three times renders its
+    # own blueprints like the oracle on that image (tex_id % 3 picks a copy)
+    pc = ofdg.default_params(width=W, height=H, mode=5, background_prep=prep, sampler=1, seed=5, num_objects=6)
+    gc = ofdg.Generator(pc)
+    gc.pool_alloc_mixed(3)
+    for k in range(3):
+        gc.pool_upload_mixed(k, images[1])
+    i0, i1, fl = ofdg.alloc_outputs(2, H, W)
+    gc.forward_counter(3, 2, i0, i1, fl)
+    gc.synchronize()
+    ctasks, cbps, cn = gc.sample_counter(3, 2)
+    qc = oracle.default_params(W, H, 5, 1, 2, 6)
+    qc.background_prep = prep
+    with oracle.detmath():
+        e0, e1, ef = oracle.render(qc, ctasks, 2, cbps, cn, images[1][None])
+    # (background_prep: the preparation record's cos / sin are float on the device - at most 1 LSB on a few pixels)
+    d0, d1 = np.abs(i0.cpu().numpy() - e0), np.abs(i1.cpu().numpy() - e1)
+    assert d0.max() <= (1 if prep else 0) and d1.max() <= (1 if prep else 0), (d0.max(), d1.max())
+    assert (d0 > 0).mean() < 0.02 and (d1 > 0).mean() < 0.02
 
 
 def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_path):
@@ -658,7 +684,7 @@ def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_pat
     lst.write_text("\n".join(paths) + "\n")
     layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
     a, b, f = layer.Forward()
-    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3))
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3, background_prep=1))  # (the layer's default)
     g.pool_alloc_mixed(3)
     for k, im in enumerate(planar):
         g.pool_upload_mixed(k, im)
@@ -686,7 +712,7 @@ def test_pool_from_list_decodes_images_like_the_ppm_loader(ofdg, tmp_path):
         planar.append(np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))
     lst = tmp_path / "images.txt"
     lst.write_text("\n".join(paths) + "\n")
-    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3))
+    g = ofdg.Generator(ofdg.default_params(width=128, height=96, mode=7, batch_size=3, background_prep=1))  # (the layer's default)
     assert g.pool_from_list(str(lst)) == 3
     assert np.array_equal(g.pool_download_all(), np.stack(planar))
     lst2 = tmp_path / "images2.txt"

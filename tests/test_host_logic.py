@@ -159,6 +159,10 @@ def test_prototxt_parser(ofdg):
     assert (p.mode, p.batch_size, p.prefetch, p.first_level_threads, p.second_level_threads) == (7, 8, 40, 8, 3)
     assert p.use_antialiasing == 1 and (p.width, p.height) == (512, 384)  # proto defaults / DGEN_WIDTH x DGEN_HEIGHT
     assert db == "/data/textures/database.txt" and ntop == 3
+    assert p.background_prep == 1   # the layer prepares backgrounds like the reference unless told otherwise (extension key)
+    p2, _, _ = ofdg.parse_prototxt('layer { type: "DataGeneration" data_generation_param { mode: 7 background_prep: false } }')
+    p3, _, _ = ofdg.parse_prototxt('layer { type: "DataGeneration" data_generation_param { mode: 7 background_prep: fast } }')
+    assert (p2.background_prep, p3.background_prep) == (0, 2)
     ext = PROTOTXT.replace("mode: 7", "mode: 5 use_antialiasing: false width: 1024 height: 768 num_objects: 32")
     p, _, _ = ofdg.parse_prototxt(ext)
     assert (p.mode, p.use_antialiasing, p.width, p.height, p.num_objects) == (5, 0, 1024, 768, 32)

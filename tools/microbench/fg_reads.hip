@@ -1,0 +1,101 @@
+// Developer micro-benchmark (not part of the product): what do the FOREGROUND texture reads of compose cost the memory
+// system by themselves?  64 x 4 strips as in compose: every wave reads background-like texels (two 16-byte groups per
+// lane from its sample's image) and writes 8 fp32 planes with non-temporal stores; a fraction of the waves ("visits",
+// 38 % with one, a third of those with two) additionally reads an object-like window - 16 B per lane at the strip's own
+// position plus eight 8-byte tap loads around it - from ANOTHER random image of the pool:
+//   independent   issued together with the background reads
+//   dependent     issued after the background reads have returned (compose: coverage -> ballot -> taps)
+//   warm          the object images come from the first 64 pool images (Infinity-Cache resident)
+// hipcc --offload-arch=gfx950 -O3 fg_reads.hip -o fg_reads
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W = 512, H = 384, B = 32, PW = 1024, PH = 768, NPOOL = 1000;
+
+__device__ __forceinline__ uint32_t hash32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+
+// MODE 0: no visits; 1: independent; 2: dependent; WARM: object images from the first 64
+template <int MODE, bool WARM, bool STORES>
+__global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ pool, float* __restrict__ out, int salt) {
+  constexpr int per_row = W / 64, per_sample = per_row * (H / 4);
+  int wg = blockIdx.x;
+  { const int xcd = wg & 7, slot = wg >> 3; wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31); }
+  const int s = wg / per_sample, t = wg - s * per_sample;
+  const int lane = threadIdx.x;
+  const int x0 = (t % per_row) * 64 + (lane & 15) * 4, y = (t / per_row) * 4 + (lane >> 4);
+  const uint32_t img = (hash32((uint32_t)s * 2654435761u + (uint32_t)salt * 40503u) >> 7) % NPOOL;
+  const uint32_t* tex = pool + (size_t)img * PW * PH;
+  // objects are blobs of ~48 x 48 px: the strips of one 64 x 48 cell share their fate and their object image
+  const uint32_t cell = hash32((uint32_t)(s * 131 + (t % per_row) * 17 + (t / per_row) / 12) * 2246822519u + (uint32_t)salt);
+  const int visits = MODE == 0 ? 0 : ((cell % 100u) < 38u ? ((cell >> 8) % 3u == 0 ? 2 : 1) : 0);  // wave-uniform
+  uint4 a = *reinterpret_cast<const uint4*>(tex + (size_t)(y + PH / 4) * PW + x0 + PW / 4);
+  uint4 b = *reinterpret_cast<const uint4*>(tex + (size_t)(y + PH / 4 + 9) * PW + x0 + PW / 4 + 12);
+  uint32_t acc = 0;
+  if (MODE == 2) {  // the visit's loads wait for the background's
+    acc = a.x ^ b.y;
+    asm volatile("" : "+v"(acc));
+  }
+  for (int v = 0; v < visits; ++v) {
+    uint32_t oimg = (hash32(cell + 77u * (uint32_t)v) >> 5) % (WARM ? 64u : (uint32_t)NPOOL);
+    const uint32_t* ot = pool + (size_t)oimg * PW * PH + (size_t)(PH / 2 - H / 2) * PW + (PW / 2 - W / 2);
+    const uint4 q = *reinterpret_cast<const uint4*>(ot + (size_t)y * PW + x0);
+    uint2 tp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tp[k] = *reinterpret_cast<const uint2*>(ot + (size_t)(y + 1 + (k >> 2) + ((acc >> 20) & 1)) * PW + x0 + 2 + (k & 3));
+    acc ^= q.x + q.y + q.z + q.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += tp[k].x * 3u + tp[k].y;
+    if (MODE == 2) asm volatile("" : "+v"(acc));  // the next visit depends on this one
+  }
+  a.x ^= acc;
+  if (!STORES) {
+    if ((a.x ^ b.x ^ a.w) == 0x12345u) out[lane] = 1.f;  // (keeps the loads alive)
+    return;
+  }
+  const size_t plane = (size_t)W * H, o = (size_t)y * W + x0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const uint32_t sh = 8 * (p % 3);
+    const uint4 q = (p & 1) ? b : a;
+    f32x4 v = {(float)((q.x >> sh) & 255u), (float)((q.y >> sh) & 255u), (float)((q.z >> sh) & 255u), (float)((q.w >> sh) & 255u)};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + ((size_t)s * 8 + p) * plane + o));
+  }
+}
+
+template <int MODE, bool WARM, bool STORES>
+static float run(const uint32_t* pool, float* out, int reps) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int grid = B * (W / 64) * (H / 4);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES>), dim3(grid), dim3(64), 0, 0, pool, out, i);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES>), dim3(grid), dim3(64), 0, 0, pool, out, 5 + i);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
+int main() {
+  uint32_t* pool = nullptr;
+  float* out = nullptr;
+  const size_t pool_bytes = (size_t)NPOOL * PW * PH * 4, out_bytes = (size_t)B * 8 * W * H * 4;
+  CK(hipMalloc((void**)&pool, pool_bytes));
+  CK(hipMalloc((void**)&out, out_bytes));
+  CK(hipMemset(pool, 0x5A, pool_bytes));
+  CK(hipDeviceSynchronize());
+  for (int round = 0; round < 2; ++round) {
+    printf("with stores : no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
+           run<0, false, true>(pool, out, 100), run<1, false, true>(pool, out, 100), run<1, true, true>(pool, out, 100),
+           run<2, false, true>(pool, out, 100), run<2, true, true>(pool, out, 100));
+    printf("reads only  : no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
+           run<0, false, false>(pool, out, 100), run<1, false, false>(pool, out, 100), run<1, true, false>(pool, out, 100),
+           run<2, false, false>(pool, out, 100), run<2, true, false>(pool, out, 100));
+  }
+  return 0;
+}

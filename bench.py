@@ -238,6 +238,13 @@ def main():
             step(i)
         gen.synchronize(stream)
         parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        # third short pass, one batch at a time (device idle between the steps): the kernels' durations with nothing
+        # else in flight - what one launch of the compose kernel takes when it has the GPU to itself
+        gen.set_profiling(2)
+        for i in range(min(args.steps, 32)):
+            step(i)
+            gen.synchronize(stream)
+        alone = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
         gen.set_profiling(0)
         alg_bytes_per_sample = 38 * W * H  # 32 B/px written (8 fp32 planes) + 6 B/px background read
         samples = args.steps * BATCH * world
@@ -267,6 +274,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "kernel_ms": compose_ms,
+                         # the same launch with the device to itself (serialised pass after the timed region)
+                         "kernel_ms_alone": alone["compose"],
+                         "frac_alone": BATCH * alg_bytes_per_sample / (alone["compose"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": BATCH * alg_bytes_per_sample,
                          # the pipeline runs independent in-order chains: compose launches of neighbouring steps overlap each
                          # other (and the preparation kernels) on the device, so a launch's duration can exceed the step;
@@ -275,7 +285,7 @@ def main():
                          "whole_step_frac": value / world * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS,
                          "note": "achieved = algorithmic bytes of one launch / its live HIP-event duration (launches overlap); "
                                  "whole_step_frac = algorithmic bytes per second of the whole pipeline / peak"},
-            "kernel_ms": parts,
+            "kernel_ms": parts, "kernel_ms_alone": alone,
             "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
         if host_sampler_rate is not None:

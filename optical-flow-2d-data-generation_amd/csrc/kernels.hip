@@ -1957,129 +1957,101 @@ __device__ __forceinline__ uint32_t bgprep_texel(const DevBgPrep& p, int u, int 
 
 // ---- background_prep = 1: the CImg chain stage by stage (DG:96-103), four u8 images -------------------------------
 //   C = crop(rotate(shift(T)))  cw x ch   bgprep_rotcrop_kernel (shift, rotate and crop are per-texel maps: fused, exact)
-//   M = resize of C along x     2W x ch   bgprep_resize_kernel<true>
-//   B = resize of M along y     2W x 2H   bgprep_resize_kernel<false>  -> the sample's background texture
-// Only what compose can read of B (DevBgPrep.r*) is produced, and of M and C what that needs (DevBgPlan).
-struct DevBgPlan {
-  int32_t cx0, cx1;  // columns of C the X pass reads
-  int32_t my0, my1;  // rows of M (= rows of C) the Y pass reads
-  int32_t ok, pad[3];
+//   M = resize of C along x     2W x ch   } bgprep_resize_kernel: every texel of B evaluates the one or two (enlarging) or
+//   B = resize of M along y     2W x 2H   } few (moving average) texels of M it needs from C, rounded to u8 as CImg stores them
+// Only what compose can read of B (DevBgPrep.r*) is produced, and of C what that needs.
+// CImg's enlarging tables (source index and weight of every destination pixel: running double sums, curr = min(n - 1,
+// curr + f), sequential by definition) depend on the source and destination lengths only: the host tabulates them once
+// for every source length below the destination's (ofdg_api.hip ensure_bgprep_tables): entry [n * S + x].
+struct DevResizeTabs {
+  const uint16_t* at_x;    // [2W][2W]
+  const double* alpha_x;
+  const uint16_t* at_y;    // [2H][2H]
+  const double* alpha_y;
 };
-// CImg get_resize(.., 3), enlarging: source index and weight of every destination pixel - running double sums
-// (curr = min(n - 1, curr + f)), sequential by definition: one lane per (sample, axis)
-__device__ inline void cimg_enlarge_table(int n, int s, int* __restrict__ at, double* __restrict__ alpha) {
-  const double f = s > 1 ? (n - 1.) / (s - 1) : 0;
-  double curr = 0, old = 0;
-  int pos = 0;
-  for (int x = 0; x < s; ++x) {
-    alpha[x] = curr - (double)(unsigned int)curr;
-    at[x] = pos;
-    old = curr;
-    curr = fmin(n - 1., curr + f);
-    pos += (int)((unsigned int)curr - (unsigned int)old);
-  }
-}
 // source range [lo, hi] a resize pass reads for destination pixels d0..d1 (n source, s destination pixels)
-__device__ inline void cimg_resize_range(int n, int s, int d0, int d1, const int* __restrict__ at, int* lo, int* hi) {
-  if (s > n) { *lo = at[d0]; *hi = min(at[d1] + 1, n - 1); }
+__device__ __forceinline__ void cimg_resize_range(int n, int s, int d0, int d1, const uint16_t* __restrict__ at, int* lo, int* hi) {
+  if (s > n) { *lo = at[(size_t)n * s + d0]; *hi = min((int)at[(size_t)n * s + d1] + 1, n - 1); }
   else if (s == n) { *lo = d0; *hi = d1; }
-  else { *lo = (int)(((long long)d0 * n) / s); *hi = (int)((((long long)(d1 + 1)) * n - 1) / s); }
+  else { *lo = (d0 * n) / s; *hi = ((d1 + 1) * n - 1) / s; }
 }
-__global__ __launch_bounds__(64) void bgprep_plan_kernel(const DevBgPrep* __restrict__ prep, int W, int H, int cap_cw, int cap_ch,
-                                                         int* __restrict__ at, double* __restrict__ alpha, DevBgPlan* __restrict__ plan,
-                                                         uint32_t* __restrict__ err) {
-  const int s = blockIdx.x, TW = 2 * W, TH = 2 * H;
-  const DevBgPrep p = prep[s];
-  int* at_x = at + (size_t)s * (TW + TH);
-  int* at_y = at_x + TW;
-  double* al_x = alpha + (size_t)s * (TW + TH);
-  double* al_y = al_x + TW;
-  const bool fits = p.cw >= 1 && p.ch >= 1 && p.cw <= cap_cw && p.ch <= cap_ch;
-  if (fits) {
-    if (threadIdx.x == 0 && p.cw < TW) cimg_enlarge_table(p.cw, TW, at_x, al_x);
-    if (threadIdx.x == 1 && p.ch < TH) cimg_enlarge_table(p.ch, TH, at_y, al_y);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    DevBgPlan q = DevBgPlan();
-    q.ok = fits ? 1 : 0;
-    if (fits) {
-      cimg_resize_range(p.ch, TH, p.ry0, p.ry1, at_y, &q.my0, &q.my1);
-      cimg_resize_range(p.cw, TW, p.rx0, p.rx1, at_x, &q.cx0, &q.cx1);
-    } else {
-      atomicOr(err, kErrBgPrepCapacity);
-    }
-    plan[s] = q;
-  }
+// the region of C (columns cx0..cx1, rows cy0..cy1) the sample's visible part of B needs; false: the crop does not fit the workspace
+__device__ __forceinline__ bool bgprep_region(const DevBgPrep& p, const DevResizeTabs& T, int TW, int TH, int cap_cw, int cap_ch,
+                                              int* cx0, int* cx1, int* cy0, int* cy1) {
+  if (!(p.cw >= 1 && p.ch >= 1 && p.cw <= cap_cw && p.ch <= cap_ch)) return false;
+  cimg_resize_range(p.ch, TH, p.ry0, p.ry1, T.at_y, cy0, cy1);
+  cimg_resize_range(p.cw, TW, p.rx0, p.rx1, T.at_x, cx0, cx1);
+  return true;
 }
 // C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y
-__global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, const DevBgPlan* __restrict__ plan,
-                                                             int cap_cw, int cap_ch, uint32_t* __restrict__ C) {
+__global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H,
+                                                             int cap_cw, int cap_ch, uint32_t* __restrict__ C, uint32_t* __restrict__ err) {
   const int s = blockIdx.y;
-  const DevBgPlan q = plan[s];
-  if (!q.ok) return;
-  const int rw_ = q.cx1 - q.cx0 + 1, rh_ = q.my1 - q.my0 + 1;
   const DevBgPrep p = prep[s];
+  int cx0, cx1, cy0, cy1;
+  if (!bgprep_region(p, T, 2 * W, 2 * H, cap_cw, cap_ch, &cx0, &cx1, &cy0, &cy1)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, kErrBgPrepCapacity);
+    return;
+  }
+  const int rw_ = cx1 - cx0 + 1, rh_ = cy1 - cy0 + 1;
   uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {  // (the region's size is only known on the device)
     const int jj = k / rw_;
-    const int j = q.my0 + jj, i = q.cx0 + (k - jj * rw_);
+    const int j = cy0 + jj, i = cx0 + (k - jj * rw_);
     const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
     const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
     Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, xc, yc);
   }
 }
-// one axis of CImg's linear get_resize on BGRX texels (see pool_resize_axis_kernel): kAlongX: C (cw x ch) -> M (2W x ch);
-// else M -> B (2W x 2H), the sample's texture
-template <bool kAlongX>
-__global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __restrict__ prep, const DevBgPlan* __restrict__ plan,
-                                                            const int* __restrict__ at, const double* __restrict__ alpha, int W, int H,
-                                                            int cap_cw, int cap_ch, const uint32_t* __restrict__ src_all,
-                                                            uint32_t* __restrict__ dst_all) {
+// one axis of CImg's linear get_resize on BGRX texels: destination pixel k of a line whose source texels are texel(j),
+// j < n; sdim = destination length.  Enlarging: (T)((1 - a) * v1 + a * v2) in double; shrinking: moving average over the
+// n * sdim grid in float, / n, truncated; same length: copy.
+template <class Texel>
+__device__ __forceinline__ uint32_t cimg_resize_texel(int n, int sdim, int k, const uint16_t* __restrict__ at, const double* __restrict__ alpha,
+                                                      Texel texel) {
+  uint32_t out = 0;
+  if (sdim == n) {
+    out = texel(k);
+  } else if (sdim > n) {
+    const int a0 = at[(size_t)n * sdim + k];
+    const double al = alpha[(size_t)n * sdim + k];
+    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
+      out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+    }
+  } else {
+    float acc[3] = {0.f, 0.f, 0.f};
+    const int lo = k * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
+    for (int j = lo / sdim; j * sdim < hi; ++j) {
+      const int a = j * sdim, b = a + sdim;
+      const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
+      const uint32_t t = texel(j);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
+  }
+  return out;
+}
+// B(x, y) = Y-resize of M(x, .), M(x, j) = X-resize of C(., j): both passes per texel of B, M never touches memory
+__global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int cap_cw,
+                                                            int cap_ch, const uint32_t* __restrict__ C, uint32_t* __restrict__ B) {
   const int s = blockIdx.y, TW = 2 * W, TH = 2 * H;
-  const DevBgPlan q = plan[s];
-  if (!q.ok) return;
   const DevBgPrep p = prep[s];
-  // destination region
-  const int dx0 = p.rx0, dx1 = p.rx1, dy0 = kAlongX ? q.my0 : p.ry0, dy1 = kAlongX ? q.my1 : p.ry1;
-  const int rw_ = dx1 - dx0 + 1, rh_ = dy1 - dy0 + 1;
-  const int n = kAlongX ? p.cw : p.ch, sdim = kAlongX ? TW : TH;  // source / destination length along the axis
-  const int sw = kAlongX ? p.cw : TW;                                 // source row pitch
-  const uint32_t* src = src_all + (kAlongX ? (size_t)s * cap_cw * cap_ch : (size_t)s * TW * cap_ch);
-  uint32_t* dst = dst_all + (kAlongX ? (size_t)s * TW * cap_ch : (size_t)s * TW * TH);
-  const int* tab = at + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
-  const double* al_tab = alpha + (size_t)s * (TW + TH) + (kAlongX ? 0 : TW);
+  if (!(p.cw >= 1 && p.ch >= 1 && p.cw <= cap_cw && p.ch <= cap_ch)) return;
+  const int rw_ = p.rx1 - p.rx0 + 1, rh_ = p.ry1 - p.ry0 + 1;
+  const uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
+  uint32_t* Bs = B + (size_t)s * TW * TH;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {
     const int yy = k / rw_;
-    const int y = dy0 + yy, x = dx0 + (k - yy * rw_);
-    const int kk = kAlongX ? x : y, line = kAlongX ? y : x;
-    auto texel = [&](int j) { return kAlongX ? src[(size_t)line * sw + j] : src[(size_t)j * sw + line]; };
-    uint32_t out = 0;
-    if (sdim == n) {
-      out = texel(kk);
-    } else if (sdim > n) {
-      const int a0 = tab[kk];
-      const double al = al_tab[kk];
-      const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
-        out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
-      }
-    } else {
-      float acc[3] = {0.f, 0.f, 0.f};
-      const int lo = kk * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
-      for (int j = lo / sdim; j * sdim < hi; ++j) {
-        const int a = j * sdim, b = a + sdim;
-        const float d = (float)((b < hi ? b : hi) - (a > lo ? a : lo));
-        const uint32_t t = texel(j);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
-    }
-    dst[(size_t)y * TW + x] = out;
+    const int y = p.ry0 + yy, x = p.rx0 + (k - yy * rw_);
+    auto m_texel = [&](int j) {  // M(x, j)
+      return cimg_resize_texel(p.cw, TW, x, T.at_x, T.alpha_x, [&](int i) { return Cs[(size_t)j * p.cw + i]; });
+    };
+    Bs[(size_t)y * TW + x] = cimg_resize_texel(p.ch, TH, y, T.at_y, T.alpha_y, m_texel);
   }
 }
 

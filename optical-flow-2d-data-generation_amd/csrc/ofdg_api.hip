@@ -78,10 +78,7 @@ struct ofdg_ctx {
     DevBuf<DevBgPrep> d_bgprep;   // background_prep: one record ...
     DevBuf<uint32_t> d_bgtex;     // ... and one prepared 2W x 2H BGRX texture per sample
     // background_prep = 1 (the CImg chain stage by stage): crop of the rotated image, X-resized image, resize tables, plan
-    DevBuf<uint32_t> d_bgC, d_bgM;
-    DevBuf<int> d_bg_at;
-    DevBuf<double> d_bg_alpha;
-    DevBuf<DevBgPlan> d_bgplan;
+    DevBuf<uint32_t> d_bgC;
     DevBuf<unsigned long long> d_blockmask;  // [2 parities][samples][64 x 8 blocks][2 frames]
     int res_objects = 0;
     int box_parity = 0;
@@ -154,6 +151,10 @@ struct ofdg_ctx {
   bool overlap = true;
   double* d_cs_tab = nullptr;
   uint32_t* d_err = nullptr;
+  // background_prep = 1: CImg's enlarging tables for every source length below 2W (x) / 2H (y), tabulated once
+  DevBuf<uint16_t> d_bg_at_x, d_bg_at_y;
+  DevBuf<double> d_bg_alpha_x, d_bg_alpha_y;
+  int bg_tab_w = 0, bg_tab_h = 0;
   uint32_t* h_err = nullptr;        // pinned copy for ofdg_poll_errors, on its own stream
   hipStream_t err_stream = nullptr;
   // profiling: ring of event sets, 6 events per launch: start/stop of geom, raster and compose,
@@ -312,7 +313,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   auto drop_slot = [](ofdg_ctx::Slot& sl) {
     sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
-    sl.d_bgC.release(); sl.d_bgM.release(); sl.d_bg_at.release(); sl.d_bg_alpha.release(); sl.d_bgplan.release();
+    sl.d_bgC.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
     if (sl.d_item_count) (void)hipFree(sl.d_item_count);
     if (sl.ev_uploaded) (void)hipEventDestroy(sl.ev_uploaded);
@@ -338,6 +339,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   c->d_cs_bps.release(); c->d_cs_nobj.release();
   if (c->d_cs_tab) (void)hipFree(c->d_cs_tab);
   if (c->d_err) (void)hipFree(c->d_err);
+  c->d_bg_at_x.release(); c->d_bg_at_y.release(); c->d_bg_alpha_x.release(); c->d_bg_alpha_y.release();
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->err_stream) (void)hipStreamDestroy(c->err_stream);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -926,6 +928,41 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   return OFDG_OK;
 }
 
+// CImg get_resize(.., 3), enlarging branch: source index and weight of every destination pixel (running double sums,
+// boundary 0) for EVERY source length n < s, entry [n * s + x]; once per context and frame size
+static int ensure_bgprep_tables(ofdg_ctx* c) {
+  const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
+  if (c->bg_tab_w == TW && c->bg_tab_h == TH) return OFDG_OK;
+  auto build = [&](int s, DevBuf<uint16_t>& d_at, DevBuf<double>& d_alpha) -> int {
+    std::vector<uint16_t> at((size_t)s * s, 0);
+    std::vector<double> alpha((size_t)s * s, 0.0);
+    for (int n = 1; n < s; ++n) {
+      const double f = s > 1 ? (n - 1.) / (s - 1) : 0;
+      double curr = 0, old = 0;
+      int pos = 0;
+      for (int x = 0; x < s; ++x) {
+        alpha[(size_t)n * s + x] = curr - (unsigned int)curr;
+        at[(size_t)n * s + x] = (uint16_t)pos;
+        old = curr;
+        curr = std::min(n - 1., curr + f);
+        pos += (int)((unsigned int)curr - (unsigned int)old);
+      }
+    }
+    HIP_OK(c, d_at.reserve(at.size()));
+    HIP_OK(c, d_alpha.reserve(alpha.size()));
+    HIP_OK(c, hipMemcpy(d_at.p, at.data(), at.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemcpy(d_alpha.p, alpha.data(), alpha.size() * sizeof(double), hipMemcpyHostToDevice));
+    return OFDG_OK;
+  };
+  if (TW > 65535 || TH > 65535) { c->err = "background_prep: frame too large for the resize tables"; return OFDG_EINVAL; }
+  HIP_OK(c, hipDeviceSynchronize());
+  int rc = build(TW, c->d_bg_at_x, c->d_bg_alpha_x);
+  if (rc == OFDG_OK) rc = build(TH, c->d_bg_at_y, c->d_bg_alpha_y);
+  if (rc != OFDG_OK) return rc;
+  c->bg_tab_w = TW; c->bg_tab_h = TH;
+  return OFDG_OK;
+}
+
 // background_prep: (upload the records of n samples and) render their 2W x 2H background
 // textures into the slot's buffer on stream `s` (bgprep_kernel)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s) {
@@ -938,10 +975,8 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
   if (staged) {
     HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
-    HIP_OK(c, sl.d_bgM.reserve((size_t)n * TW * cap_ch));
-    HIP_OK(c, sl.d_bg_at.reserve((size_t)n * (TW + TH)));
-    HIP_OK(c, sl.d_bg_alpha.reserve((size_t)n * (TW + TH)));
-    HIP_OK(c, sl.d_bgplan.reserve(n));
+    int rct = ensure_bgprep_tables(c);
+    if (rct != OFDG_OK) return rct;
   }
   if (host_records) {
     HIP_OK(c, hipMemcpyAsync(sl.d_bgprep.p, host_records, (size_t)n * sizeof(DevBgPrep), hipMemcpyHostToDevice, s));
@@ -952,14 +987,11 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
-  hipLaunchKernelGGL(bgprep_plan_kernel, dim3(n), dim3(64), 0, s, sl.d_bgprep.p, W, H, cap_cw, cap_ch, sl.d_bg_at.p, sl.d_bg_alpha.p,
-                     sl.d_bgplan.p, c->d_err);
-  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p, cap_cw, cap_ch,
-                     sl.d_bgC.p);
-  hipLaunchKernelGGL(bgprep_resize_kernel<true>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
-                     sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgC.p, sl.d_bgM.p);
-  hipLaunchKernelGGL(bgprep_resize_kernel<false>, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, sl.d_bgplan.p,
-                     sl.d_bg_at.p, sl.d_bg_alpha.p, W, H, cap_cw, cap_ch, sl.d_bgM.p, sl.d_bgtex.p);
+  const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
+  hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
+                     c->d_err);
+  hipLaunchKernelGGL(bgprep_resize_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
+                     sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
   return OFDG_OK;
 }

@@ -18,9 +18,11 @@ constexpr int W = 512, H = 384, B = 32, PW = 1024, PH = 768, NPOOL = 1000;
 
 __device__ __forceinline__ uint32_t hash32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
 
-// MODE 0: no visits; 1: independent; 2: dependent; WARM: object images from the first 64
-template <int MODE, bool WARM, bool STORES>
-__global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ pool, float* __restrict__ out, int salt) {
+// MODE 0: no visits; 1: independent; 2: dependent; 3: independent, the window as two wide row loads (6 rows x 272 B:
+// what staging the window in LDS would issue); WARM: object images from the first 64
+template <int MODE, bool WARM, bool STORES, int BPT>
+__global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ pool_, float* __restrict__ out, int salt) {
+  const char* pool = reinterpret_cast<const char*>(pool_);
   constexpr int per_row = W / 64, per_sample = per_row * (H / 4);
   int wg = blockIdx.x;
   { const int xcd = wg & 7, slot = wg >> 3; wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31); }
@@ -28,12 +30,19 @@ __global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ poo
   const int lane = threadIdx.x;
   const int x0 = (t % per_row) * 64 + (lane & 15) * 4, y = (t / per_row) * 4 + (lane >> 4);
   const uint32_t img = (hash32((uint32_t)s * 2654435761u + (uint32_t)salt * 40503u) >> 7) % NPOOL;
-  const uint32_t* tex = pool + (size_t)img * PW * PH;
+  const char* tex = pool + (size_t)img * PW * PH * BPT;
   // objects are blobs of ~48 x 48 px: the strips of one 64 x 48 cell share their fate and their object image
   const uint32_t cell = hash32((uint32_t)(s * 131 + (t % per_row) * 17 + (t / per_row) / 12) * 2246822519u + (uint32_t)salt);
   const int visits = MODE == 0 ? 0 : ((cell % 100u) < 38u ? ((cell >> 8) % 3u == 0 ? 2 : 1) : 0);  // wave-uniform
-  uint4 a = *reinterpret_cast<const uint4*>(tex + (size_t)(y + PH / 4) * PW + x0 + PW / 4);
-  uint4 b = *reinterpret_cast<const uint4*>(tex + (size_t)(y + PH / 4 + 9) * PW + x0 + PW / 4 + 12);
+  uint4 a = make_uint4(0, 0, 0, 0), b = a;
+  if (BPT == 4) {
+    a = *reinterpret_cast<const uint4*>(tex + ((size_t)(y + PH / 4) * PW + x0 + PW / 4) * 4);
+    b = *reinterpret_cast<const uint4*>(tex + ((size_t)(y + PH / 4 + 9) * PW + x0 + PW / 4 + 12) * 4);
+  } else {  // 4 texels = 12 bytes, 4-byte aligned (x0 is a multiple of 4)
+    const uint3 a3 = *reinterpret_cast<const uint3*>(tex + ((size_t)(y + PH / 4) * PW + x0 + PW / 4) * 3);
+    const uint3 b3 = *reinterpret_cast<const uint3*>(tex + ((size_t)(y + PH / 4 + 9) * PW + x0 + PW / 4 + 12) * 3);
+    a = make_uint4(a3.x, a3.y, a3.z, a3.x ^ a3.y); b = make_uint4(b3.x, b3.y, b3.z, b3.y ^ b3.z);
+  }
   uint32_t acc = 0;
   if (MODE == 2) {  // the visit's loads wait for the background's
     acc = a.x ^ b.y;
@@ -41,11 +50,24 @@ __global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ poo
   }
   for (int v = 0; v < visits; ++v) {
     uint32_t oimg = (hash32(cell + 77u * (uint32_t)v) >> 5) % (WARM ? 64u : (uint32_t)NPOOL);
-    const uint32_t* ot = pool + (size_t)oimg * PW * PH + (size_t)(PH / 2 - H / 2) * PW + (PW / 2 - W / 2);
-    const uint4 q = *reinterpret_cast<const uint4*>(ot + (size_t)y * PW + x0);
+    const char* ot = pool + ((size_t)oimg * PW * PH + (size_t)(PH / 2 - H / 2) * PW + (PW / 2 - W / 2)) * BPT;
+    uint4 q;
+    if (MODE == 3) {
+      const int y4 = y & ~3, xb = x0 & ~63;       // the strip's origin
+      uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+      const int r = lane / 17, cc = lane - r * 17;  // 3 rows of 17 x 16 B per load
+      if (r < 3) {
+        w0 = *reinterpret_cast<const uint4*>(ot + ((size_t)(y4 + r) * PW + xb) * 4 + cc * 16);
+        w1 = *reinterpret_cast<const uint4*>(ot + ((size_t)(y4 + 3 + r) * PW + xb) * 4 + cc * 16);
+      }
+      acc ^= w0.x + w0.y + w0.z + w0.w + w1.x + w1.y + w1.z + w1.w;
+      continue;
+    }
+    if (BPT == 4) q = *reinterpret_cast<const uint4*>(ot + ((size_t)y * PW + x0) * 4);
+    else { const uint3 q3 = *reinterpret_cast<const uint3*>(ot + ((size_t)y * PW + x0) * 3); q = make_uint4(q3.x, q3.y, q3.z, q3.x + q3.z); }
     uint2 tp[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tp[k] = *reinterpret_cast<const uint2*>(ot + (size_t)(y + 1 + (k >> 2) + ((acc >> 20) & 1)) * PW + x0 + 2 + (k & 3));
+    for (int k = 0; k < 8; ++k) tp[k] = *reinterpret_cast<const uint2*>(ot + ((size_t)(y + 1 + (k >> 2) + ((acc >> 20) & 1)) * PW + x0 + 2 + (k & 3)) * BPT);  // (BPT 3: byte-aligned 8-byte loads)
     acc ^= q.x + q.y + q.z + q.w;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc += tp[k].x * 3u + tp[k].y;
@@ -66,14 +88,14 @@ __global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ poo
   }
 }
 
-template <int MODE, bool WARM, bool STORES>
+template <int MODE, bool WARM, bool STORES, int BPT = 4>
 static float run(const uint32_t* pool, float* out, int reps) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int grid = B * (W / 64) * (H / 4);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES>), dim3(grid), dim3(64), 0, 0, pool, out, i);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES, BPT>), dim3(grid), dim3(64), 0, 0, pool, out, i);
   (void)hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES>), dim3(grid), dim3(64), 0, 0, pool, out, 5 + i);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fg_kernel<MODE, WARM, STORES, BPT>), dim3(grid), dim3(64), 0, 0, pool, out, 5 + i);
   (void)hipEventRecord(e1, 0);
   (void)hipEventSynchronize(e1);
   float ms = 0;
@@ -93,6 +115,11 @@ int main() {
     printf("with stores : no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
            run<0, false, true>(pool, out, 100), run<1, false, true>(pool, out, 100), run<1, true, true>(pool, out, 100),
            run<2, false, true>(pool, out, 100), run<2, true, true>(pool, out, 100));
+    printf("3-byte texel: no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
+           run<0, false, true, 3>(pool, out, 100), run<1, false, true, 3>(pool, out, 100), run<1, true, true, 3>(pool, out, 100),
+           run<2, false, true, 3>(pool, out, 100), run<2, true, true, 3>(pool, out, 100));
+    printf("wide loads  : independent cold %6.1f  warm %6.1f   (two 16-byte row loads per visit instead of 16 B + eight taps)\n",
+           run<3, false, true>(pool, out, 100), run<3, true, true>(pool, out, 100));
     printf("reads only  : no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
            run<0, false, false>(pool, out, 100), run<1, false, false>(pool, out, 100), run<1, true, false>(pool, out, 100),
            run<2, false, false>(pool, out, 100), run<2, true, false>(pool, out, 100));

@@ -908,13 +908,6 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     mask0 = mm.x; mask1 = mm.y;
   }
   unsigned long long omask = mask0 | mask1;
-  if constexpr (kDeform) {
-    // mode 9 runs two kernels: compose_rigid*_m9_kernel renders the strips no warp field touches, this one the others
-    bool touched = smp.bg_deform != 0;
-    for (unsigned long long m = omask; m && !touched; m &= m - 1)
-      touched = (samples[s].shape_of[__ffsll((long long)m) - 1] & kShapeDeform) != 0;  // (from memory: indexing the register copy would spill it)
-    if (!touched) return;  // (wave-uniform)
-  }
 
   const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
   const size_t slot_bytes = (size_t)W * H;
@@ -1420,9 +1413,7 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 #endif
 constexpr int kPre = OFDG_X_PRE;  // objects of a block whose header / coverage / record are fetched ahead of their visit
 
-// kMode9: the kernel renders only the strips no warp field touches (background and every object of the block rigid) and
-// leaves the others to compose_deform*_kernel, which skips these.
-template <bool kPow2, bool kMode9 = false>
+template <bool kPow2>
 __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
                                               const DevObject* __restrict__ objects, const uint8_t* __restrict__ cov,
                                               int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
@@ -1451,11 +1442,11 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   // ---- scalar stage 1: sample (+ background) record and block masks, requested in ONE batch ----
   // (the compiler loads a struct field where its first use is; an empty asm statement that names every value right here
   //  makes that one place: one s_waitcnt for the whole record instead of one per use site)
-  struct SmpRec { int first_object, first_shape, bg_deform; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; } smp;
+  struct SmpRec { int first_object, first_shape; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; } smp;
   unsigned long long mask0, mask1;
   {
     const DevSample& R = samples[s];
-    smp.first_object = R.first_object; smp.first_shape = R.first_shape; smp.bg_deform = kMode9 ? R.bg_deform : 0;
+    smp.first_object = R.first_object; smp.first_shape = R.first_shape;
     smp.bg_motion = R.bg_motion; smp.bg_tex_inv = R.bg_tex_inv; smp.bg_tex_base = R.bg_tex_base;
     const int nby = (H + kBandRows - 1) / kBandRows;
     const int brow = (ty0 + (sub >> 1) * kBandRows) / kBandRows;
@@ -1478,11 +1469,6 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
     const uint32_t w = shape_tab[(oi - 1) >> 1];
     return ((oi - 1) & 1) ? (w >> 16) : (w & 0xFFFFu);
   };
-  if constexpr (kMode9) {  // a strip a warp field touches belongs to the deform kernel (wave-uniform: the whole wave leaves)
-    if (smp.bg_deform != 0) return;
-    for (unsigned long long m = omask; m; m &= m - 1)
-      if (shape_entry(__ffsll((long long)m)) & kShapeDeform) return;
-  }
   int pre_oi[kPre];
   uint32_t pre_sh[kPre];
   {
@@ -1523,7 +1509,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   for (int k = 0; k < kPre; ++k) {
     pre_c0[k] = 0; pre_c1[k] = 0; pre_rec[k] = 0;
     if (!(pre_sh[k] & kShapeComposite)) {  // a simple object (wave-uniform)
-      const uint8_t* c = cov + (size_t)(smp.first_shape + (int)(pre_sh[k] & kShapeSlotMask)) * 2 * slot_bytes;
+      const uint8_t* c = cov + (size_t)(smp.first_shape + (int)pre_sh[k]) * 2 * slot_bytes;
       if (inside) {
         if ((mask0 >> (pre_oi[k] - 1)) & 1ull) pre_c0[k] = *reinterpret_cast<const uint32_t*>(c + pix);
         if ((mask1 >> (pre_oi[k] - 1)) & 1ull) pre_c1[k] = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
@@ -1588,7 +1574,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
     } else {
       sh = shape_entry(oi);
       if (!(sh & kShapeComposite)) {
-        const uint8_t* c = cov + (size_t)(smp.first_shape + (int)(sh & kShapeSlotMask)) * 2 * slot_bytes;
+        const uint8_t* c = cov + (size_t)(smp.first_shape + (int)sh) * 2 * slot_bytes;
         if (inside) {
           if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
           if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
@@ -1750,23 +1736,6 @@ __global__ __launch_bounds__(64) void compose_rigid_kernel(
     float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
   compose_rigid<false>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
                        flow, frames, item_count);
-}
-// mode 9: the strips no warp field touches (the others: compose_deform*_kernel)
-__global__ __launch_bounds__(64) void compose_rigid_m9_kernel(
-    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
-    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
-    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_rigid<false, true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0,
-                             img1, flow, frames, item_count);
-}
-__global__ __launch_bounds__(64) void compose_rigid_pow2_m9_kernel(
-    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
-    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
-    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_rigid<true, true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0,
-                            img1, flow, frames, item_count);
 }
 // W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads.
 __global__ __launch_bounds__(64) OFDG_X_ATTR void compose_rigid_pow2_kernel(

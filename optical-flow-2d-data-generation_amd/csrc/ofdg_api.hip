@@ -889,25 +889,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
   hipEvent_t k_start = nullptr, k_stop = ev ? ev[5] : done;
   static const bool old_compose = std::getenv("OFDG_OLD_COMPOSE") != nullptr;  // A/B: the general kernel (compose_tile) for the rigid modes too
-  if (c->prm.mode == 9) {
-    // two launches, in order: the strips no warp field touches (fast rigid kernel), then the others; every strip is
-    // written by exactly one of them.  The stop event rides on the second.
-    if ((W & (W - 1)) == 0) {
-      hipExtLaunchKernelGGL(compose_rigid_pow2_m9_kernel, dim3(compose_grid), dim3(64), 0, CS, nullptr, nullptr, 0, sl.d_samples.p, box_cur,
-                            sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                            d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
-      hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
-                            sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
-                            sl.d_item_count);
-    } else {
-      hipExtLaunchKernelGGL(compose_rigid_m9_kernel, dim3(compose_grid), dim3(64), 0, CS, nullptr, nullptr, 0, sl.d_samples.p, box_cur,
-                            sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                            d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
-      hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
-                            sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
-                            sl.d_item_count);
-    }
-  }
+  if (c->prm.mode == 9 && (W & (W - 1)) == 0)
+    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_item_count);
+  else if (c->prm.mode == 9)
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_item_count);
   else if (!old_compose && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_rigid_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
                           sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,

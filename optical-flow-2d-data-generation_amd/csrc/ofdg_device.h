@@ -77,16 +77,13 @@ struct DevSample {
   uint64_t bg_tex_base;  // = objects[first_object].tex_base
   int32_t bg_deform;
   int32_t pad;
-  // foreground object k (bit k of the block masks): first outline slot relative to first_shape; bit 15 = composite,
-  // bit 14 = deforms (mode 9).
+  // foreground object k (bit k of the block masks): first outline slot relative to first_shape; bit 15 = composite.
   // In the same record as the matrices above: by the time a wave knows its block's objects these lines are in the
   // scalar cache, and the coverage of a simple object can be fetched without first reading the object's own record.
   uint16_t shape_of[kMaxFgObjects];
 };
 static_assert(sizeof(DevSample) == 256, "compose reads the sample record as 128 + 128 bytes");
 constexpr uint16_t kShapeComposite = 0x8000u;
-constexpr uint16_t kShapeDeform = 0x4000u;   // mode 9: the object is re-sampled through a warp crop (its strips belong to the deform kernel)
-constexpr uint16_t kShapeSlotMask = 0x3FFFu;
 
 // The tail of a DevObject as compose reads it ahead of a visit (one 32-byte scalar load at offset 96).
 struct DevObjectHdr {

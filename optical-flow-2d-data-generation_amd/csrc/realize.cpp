@@ -226,7 +226,7 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       }
       {
         const int local = (int)out->objects.size() - smp.first_object - 1;  // bit of the block masks
-        smp.shape_of[local] = (uint16_t)((o.first_shape - smp.first_shape) | (o.kind == 2 ? kShapeComposite : 0) | (o.deform ? kShapeDeform : 0));
+        smp.shape_of[local] = (uint16_t)((o.first_shape - smp.first_shape) | (o.kind == 2 ? kShapeComposite : 0));
       }
       out->objects.push_back(o);
     }

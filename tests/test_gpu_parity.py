@@ -300,10 +300,11 @@ def test_full_size_properties(ofdg):
     assert float(d2x.abs().max()) < 1e-4 and float(d2y.abs().max()) < 1e-4
 
 
-def test_config5_large_pool_resident_in_hbm(ofdg):
+def test_config5_large_pool_resident_in_hbm(ofdg, oracle):
     """BASELINE config 5 shape: 10 000 textures of 1 MP (1024x1024 BGRX = 42 GB) resident in HBM, mode 7,
     512x384, one rank's batch of 32 from the counter sampler.  Properties: repeatable, integer frames in
-    [0, 255], finite flow, and the textures actually come from all over the pool."""
+    [0, 255], finite flow, the textures actually come from all over the pool - and two samples of the batch against
+    the oracle at full size (the oracle gets a host pool of just the images those samples use, texture ids re-indexed)."""
     torch = torch_mod()
     W, H, B = 512, 384, 32
     g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=3, batch_size=B))
@@ -322,6 +323,23 @@ def test_config5_large_pool_resident_in_hbm(ofdg):
     tasks, bps, n = g.sample_counter(1000, B)
     tex = {bps[t.background].tex_id % 10000 for t in tasks}
     assert len(tex) > B // 2 and max(tex) > 5000
+    for sidx in (0, B - 1):
+        t = tasks[sidx]
+        used = [t.background] + list(range(t.first_object, t.first_object + t.n_objects))
+        for k in range(t.n_objects):
+            b = bps[t.first_object + k]
+            used += list(range(b.first_component, b.first_component + b.n_components))
+        images = sorted({bps[i].tex_id % 10000 for i in used})
+        host_pool = np.stack([g.pool_download(i) for i in images])
+        sub = (ofdg.Blueprint * n)()
+        C.memmove(sub, bps, C.sizeof(sub))
+        for i in used:                                 # tex_id % len(images) picks the same image in the small pool
+            sub[i].tex_id = images.index(bps[i].tex_id % 10000)
+        q = oracle.default_params(W, H, 7, 1, 1, 0)
+        with oracle.detmath():
+            e0, e1, ef = oracle.render(q, (ofdg.Task * 1)(t), 1, sub, n, host_pool)
+        assert np.array_equal(i0[sidx].cpu().numpy(), e0[0]) and np.array_equal(i1[sidx].cpu().numpy(), e1[0])
+        assert ulp_diff(fl[sidx].cpu().numpy(), ef[0]).max() <= 1
 
 
 LAYER_PROTOTXT = '''

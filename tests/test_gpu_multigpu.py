@@ -91,3 +91,21 @@ def test_comm_joins_through_a_key_value_store(ofdg):
     su, table = c.bcast_setup(g)
     assert su.n_table == 2 and su.seed == 5
     c.close()
+
+
+def test_chain_count_follows_the_hardware_queue_setting(ofdg, monkeypatch):
+    """A process started with GPU_MAX_HW_QUEUES >= 8 gets four chains (one hardware queue each), otherwise three;
+    OFDG_CHAINS overrides (the library only reads the variable - HIP itself reads it when the runtime starts)."""
+    def chains(**env):
+        for k in ("GPU_MAX_HW_QUEUES", "OFDG_CHAINS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = ofdg.Generator(ofdg.default_params(width=64, height=48, mode=5))
+        n = g.num_chains()
+        g.close()
+        return n
+    assert chains() == 3
+    assert chains(GPU_MAX_HW_QUEUES="8") == 4
+    assert chains(GPU_MAX_HW_QUEUES="4") == 3
+    assert chains(GPU_MAX_HW_QUEUES="8", OFDG_CHAINS="2") == 2

@@ -580,6 +580,27 @@ def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool, pr
     assert (c0 != e0).mean() > 0.02
 
 
+def test_background_prep_zoom_beyond_the_workspace_is_reported(ofdg, oracle):
+    """background_prep = 1 keeps workspaces for crops of the rotated image up to zoom 0.75 (the sampler draws
+    0.8 .. 1.2).  A caller's blueprint with a smaller zoom must not be rendered wrongly in silence: the device flags
+    it, ofdg_synchronize / ofdg_poll_errors report OFDG_ECAPACITY, and the next batch renders normally."""
+    W, H = 128, 96
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, background_prep=1))
+    g.pool_synthetic(3, 256, 192, 9)
+    tasks, bps, n = oracle.Sampler(5, W, H).next(2)
+    good = render_gpu(ofdg, g, tasks, 2, bps, n)
+    bps[tasks[1].background].tex_scale = 0.5          # crop of 2W/0.5 = 4W columns
+    i0, i1, fl = ofdg.alloc_outputs(2, H, W)
+    g.render(tasks, 2, bps, n, i0, i1, fl)
+    with pytest.raises(ofdg.OfdgError) as e:
+        g.synchronize()
+    assert e.value.code == ofdg.ECAPACITY and "background_prep" in str(e.value)
+    bps[tasks[1].background].tex_scale = 0.9
+    g.render(tasks, 2, bps, n, i0, i1, fl)
+    g.synchronize()                                     # (the flag was cleared by the report)
+    assert np.array_equal(i0[0].cpu().numpy(), good[0][0])  # sample 0 was not touched by the change
+
+
 @pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
 def test_background_prep_full_size_and_counter_sampler(ofdg, oracle, prep):
     """512x384 with 1024x768 pool images; ref-sampler blueprints bit-exact, then the device counter sampler

@@ -638,13 +638,22 @@ __device__ __forceinline__ uint32_t blend_px(uint32_t d, uint32_t s, uint32_t m)
 }
 
 // MovingObjectComposite::renderMasks, strict fp32 (DG:606, 626)
+// (float)u / 255.f, correctly rounded, for a byte u: the product with rn(1/255) is wrong for 126 of the 256 bytes, one
+// Newton step on it (exact residual through an fma) is right for all of them (tests: the exhaustive byte-formula test
+// against the oracle's division; tools/check_q255.py derives it).  3 VALU instructions instead of the ~10 of a division -
+// a composite evaluates 32 of these per component and pixel quad.
+__device__ __forceinline__ float byte_over_255(int u) {
+  const float fu = (float)u, c = 0x1.010102p-8f;  // rn(1 / 255)
+  const float q0 = __fmul_rn(fu, c);
+  return __fmaf_rn(__fmaf_rn(-q0, 255.f, fu), c, q0);
+}
 __device__ __forceinline__ int comp_add(int u, int v) {
-  const float fu = __fdiv_rn((float)u, 255.f), fv = __fdiv_rn((float)v, 255.f);
+  const float fu = byte_over_255(u), fv = byte_over_255(v);
   const float t = __fmul_rn(__fsub_rn(1.f, fu), __fsub_rn(1.f, fv));
   return (int)(unsigned char)__fmul_rn(255.f, __fsub_rn(1.f, t));
 }
 __device__ __forceinline__ int comp_sub(int u, int v) {
-  const float fu = __fdiv_rn((float)u, 255.f), fv = __fdiv_rn((float)v, 255.f);
+  const float fu = byte_over_255(u), fv = byte_over_255(v);
   return (int)(unsigned char)__fmul_rn(255.f, __fmul_rn(fu, __fsub_rn(1.f, fv)));
 }
 

@@ -319,3 +319,14 @@ def test_oracle_detmath_switch_only_touches_the_last_bit(oracle):
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, z)                                   # the switch is restored
         assert (x != y).mean() < 1e-2
+
+
+def test_division_free_byte_quotient_is_the_correctly_rounded_one():
+    """kernels.hip byte_over_255 replaces (float)u / 255.f by a product and one Newton step: exact for all 256 bytes
+    (the bare product is not), so the composite masks' strict-fp32 chain is unchanged (DG:606, 626)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_q255", os.path.join(os.path.dirname(__file__), "..", "tools", "check_q255.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mul, newton = mod.newton_wrong()
+    assert newton == [] and len(mul) > 0

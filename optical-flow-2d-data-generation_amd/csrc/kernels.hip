@@ -2004,13 +2004,29 @@ __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __
   }
   const int rw_ = cx1 - cx0 + 1, rh_ = cy1 - cy0 + 1;
   uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
+  const float inv_rw = 1.0f / (float)rw_;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {  // (the region's size is only known on the device)
-    const int jj = k / rw_;
-    const int j = cy0 + jj, i = cx0 + (k - jj * rw_);
+    int jj = (int)((float)k * inv_rw);  // k / rw_ (k < 2^22: the float quotient is off by one at most)
+    int ii = k - jj * rw_;
+    if (ii < 0) { --jj; ii += rw_; } else if (ii >= rw_) { ++jj; ii -= rw_; }
+    const int j = cy0 + jj, i = cx0 + ii;
     const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
     const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
     Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, xc, yc);
   }
+}
+// a / d correctly rounded for operands that need none of the IEEE division's range handling (here 0 <= a < 2^31,
+// 1 <= d < 2^16): the compiler's own expansion of a / d - v_rcp_f32, two fma on the reciprocal, a product and four fma on
+// the quotient - without v_div_scale / v_div_fixup, and with the reciprocal's part computed once per divisor.
+struct UniformDivisor { float d, r; };
+__device__ __forceinline__ UniformDivisor make_divisor(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  return {d, __fmaf_rn(__fmaf_rn(-d, r0, 1.f), r0, r0)};
+}
+__device__ __forceinline__ float div_rn(float a, const UniformDivisor& u) {
+  float q = __fmul_rn(a, u.r);
+  q = __fmaf_rn(__fmaf_rn(-u.d, q, a), u.r, q);
+  return __fmaf_rn(__fmaf_rn(-u.d, q, a), u.r, q);
 }
 // one axis of CImg's linear get_resize on BGRX texels: destination pixel k of a line whose source texels are texel(j),
 // j < n; sdim = destination length.  Enlarging: (T)((1 - a) * v1 + a * v2) in double; shrinking: moving average over the
@@ -2040,27 +2056,50 @@ __device__ __forceinline__ uint32_t cimg_resize_texel(int n, int sdim, int k, co
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)((t >> (8 * c)) & 255u), d));
     }
+    const UniformDivisor dn = make_divisor((float)n);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)__fdiv_rn(acc[c], (float)n) << (8 * c);
+    for (int c = 0; c < 3; ++c) out |= (uint32_t)(unsigned char)div_rn(acc[c], dn) << (8 * c);
   }
   return out;
 }
-// B(x, y) = Y-resize of M(x, .), M(x, j) = X-resize of C(., j): both passes per texel of B, M never touches memory
+// B(x, y) = Y-resize of M(x, .), M(x, j) = X-resize of C(., j); M never touches memory.  The kernel is bound by its
+// arithmetic (≈ 100 VALU instructions per texel, 12 M texels per batch), so a thread renders kResizeRun consecutive rows
+// of one column and evaluates every row of M they share ONCE (one more than the run when enlarging, at most 4/3 of it
+// + 1 when shrinking), parked in the thread's own LDS column - an indexable scratch: registers cannot be indexed by a
+// run-time row.  (Issuing a run's loads together, or four texels per thread in bgprep_rotcrop_kernel, made both
+// kernels slower: profiles/r02_ab_background_prep_kernels.txt.)
+constexpr int kResizeRun = 4, kResizeMaxM = 8;
 __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int cap_cw,
                                                             int cap_ch, const uint32_t* __restrict__ C, uint32_t* __restrict__ B) {
-  const int s = blockIdx.y, TW = 2 * W, TH = 2 * H;
+  __shared__ uint32_t s_m[kResizeMaxM][256];
+  const int s = blockIdx.y, TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
   const DevBgPrep p = prep[s];
   if (!(p.cw >= 1 && p.ch >= 1 && p.cw <= cap_cw && p.ch <= cap_ch)) return;
   const int rw_ = p.rx1 - p.rx0 + 1, rh_ = p.ry1 - p.ry0 + 1;
+  const int runs = (rh_ + kResizeRun - 1) / kResizeRun;
   const uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
   uint32_t* Bs = B + (size_t)s * TW * TH;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {
-    const int yy = k / rw_;
-    const int y = p.ry0 + yy, x = p.rx0 + (k - yy * rw_);
-    auto m_texel = [&](int j) {  // M(x, j)
+  const float inv_rw = 1.0f / (float)rw_;
+  for (int k = blockIdx.x * blockDim.x + tid; k < runs * rw_; k += gridDim.x * blockDim.x) {
+    int rr = (int)((float)k * inv_rw);  // k / rw_ (k < 2^22: the float quotient is off by one at most)
+    int xo = k - rr * rw_;
+    if (xo < 0) { --rr; xo += rw_; } else if (xo >= rw_) { ++rr; xo -= rw_; }
+    const int x = p.rx0 + xo, y0 = p.ry0 + rr * kResizeRun, y1 = min(y0 + kResizeRun - 1, p.ry1);
+    auto c_row = [&](int j) {  // M(x, j)
       return cimg_resize_texel(p.cw, TW, x, T.at_x, T.alpha_x, [&](int i) { return Cs[(size_t)j * p.cw + i]; });
     };
-    Bs[(size_t)y * TW + x] = cimg_resize_texel(p.ch, TH, y, T.at_y, T.alpha_y, m_texel);
+    int jlo, jhi;
+    cimg_resize_range(p.ch, TH, y0, y1, T.at_y, &jlo, &jhi);
+    if (jhi - jlo < kResizeMaxM) {
+#pragma unroll
+      for (int m = 0; m < kResizeMaxM; ++m)
+        if (jlo + m <= jhi) s_m[m][tid] = c_row(jlo + m);
+#pragma unroll
+      for (int r = 0; r < kResizeRun; ++r)
+        if (y0 + r <= y1) Bs[(size_t)(y0 + r) * TW + x] = cimg_resize_texel(p.ch, TH, y0 + r, T.at_y, T.alpha_y, [&](int j) { return s_m[j - jlo][tid]; });
+    } else {  // (a crop beyond 4/3 of the texture is refused before it gets here; kept for safety)
+      for (int y = y0; y <= y1; ++y) Bs[(size_t)y * TW + x] = cimg_resize_texel(p.ch, TH, y, T.at_y, T.alpha_y, c_row);
+    }
   }
 }
 

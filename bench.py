@@ -283,6 +283,9 @@ def main():
                          # launches in flight on average = kernel_ms / ms_per_step
                          "launches_in_flight": compose_ms / (dt / args.steps * 1e3),
                          "whole_step_frac": value / world * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS,
+                         # the two halves of the algorithmic bytes by themselves (32 B/px written, 6 B/px read)
+                         "whole_step_write_frac": value / world * 32 * W * H / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_read_frac": value / world * 6 * W * H / 1e9 / HBM_PEAK_GBS,
                          "note": "achieved = algorithmic bytes of one launch / its live HIP-event duration (launches overlap); "
                                  "whole_step_frac = algorithmic bytes per second of the whole pipeline / peak"},
             "kernel_ms": parts, "kernel_ms_alone": alone,

@@ -40,6 +40,29 @@ __global__ __launch_bounds__(64) void strip_kernel(const uint32_t* __restrict__ 
   }
 }
 
+// the ceiling: the same bytes as one contiguous fill, 16 bytes per lane, grid-stride (NT: non-temporal stores)
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ out, size_t n4, float v) {
+  f32x4 val = {v, v + 1, v + 2, v + 3};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    if (NT) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(out) + i);
+    else reinterpret_cast<f32x4*>(out)[i] = val;
+  }
+}
+template <bool NT>
+static float run_fill(float* out, size_t bytes, int reps) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fill_kernel<NT>), dim3(256 * 16), dim3(256), 0, 0, out, bytes / 16, (float)i);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fill_kernel<NT>), dim3(256 * 16), dim3(256), 0, 0, out, bytes / 16, (float)i);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
 template <int SW, int SH, bool READS>
 static float run(const uint32_t* pool, float* out, int reps) {
   hipEvent_t e0, e1;
@@ -65,6 +88,7 @@ int main() {
   CK(hipDeviceSynchronize());
   const double mb_w = out_bytes / 1e6, mb_r = (double)B * W * H * 32 / 4 / 1e6;
   printf("per launch: %.1f MB written, %.1f MB of texel reads requested\n", mb_w, mb_r);
+  printf("contiguous fill of the same bytes: non-temporal stores %6.1f us, plain stores %6.1f us\n", run_fill<true>(out, out_bytes, 100), run_fill<false>(out, out_bytes, 100));
   for (int round = 0; round < 2; ++round) {
     printf("stores only : 64x4 %6.1f us   128x2 %6.1f us   256x1 %6.1f us\n", run<64, 4, false>(pool, out, 100), run<128, 2, false>(pool, out, 100), run<256, 1, false>(pool, out, 100));
     printf("with reads  : 64x4 %6.1f us   128x2 %6.1f us   256x1 %6.1f us\n", run<64, 4, true>(pool, out, 100), run<128, 2, true>(pool, out, 100), run<256, 1, true>(pool, out, 100));

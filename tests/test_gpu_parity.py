@@ -580,6 +580,30 @@ def test_background_prep_matches_oracle_small(ofdg, oracle, mode, size, pool, pr
     assert (c0 != e0).mean() > 0.02
 
 
+@pytest.mark.parametrize("zoom", [0.8, 0.93, 1.0, 1.07, 1.2])
+def test_background_prep_every_resize_branch(ofdg, oracle, zoom):
+    """The CImg resize of the chain takes a different branch per axis for a crop larger than, equal to and smaller than
+    the 2W x 2H texture: moving average (zoom < 1; the kernel divides by the source length with the division expansion
+    minus its range handling, div_rn), copy, linear with the tabulated running sums (zoom > 1).  Every background of the
+    batch gets the same zoom here; bit-exact against the oracle's true divisions, 160 x 100 (runs of four rows that end
+    inside the read region, a width that is no power of two)."""
+    W, H, B = 160, 100, 4
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(3, 384, 256, 9)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    for t in tasks:
+        bps[t.background].tex_scale = zoom
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
+    assert ulp_diff(got[2], ef).max() == 0
+
+
 def test_background_prep_zoom_beyond_the_workspace_is_reported(ofdg, oracle):
     """background_prep = 1 keeps workspaces for crops of the rotated image up to zoom 0.75 (the sampler draws
     0.8 .. 1.2).  A caller's blueprint with a smaller zoom must not be rendered wrongly in silence: the device flags

@@ -116,6 +116,7 @@ struct ofdg_ctx {
   struct Chain {
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> cov;
+    DevBuf<uint32_t> layer;  // rigid modes: [object][frame][H][W] texel | coverage << 24 (raster_kernel's layer pass)
     Slot slot;
     Stage stage;
     hipEvent_t ev_prep = nullptr;  // coverage ready (hand-over to a caller's stream)
@@ -290,9 +291,9 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   // fail early (and loudly) if the gfx950 code object is not usable on this device
   {
     hipFuncAttributes fa;
-    e = hipFuncGetAttributes(&fa, (const void*)compose_kernel);
+    e = hipFuncGetAttributes(&fa, (const void*)compose_rigid_kernel);
     if (e != hipSuccess) {
-      g_create_error = std::string("compose_kernel is not loadable (is the gfx950 code object present?): ") + hipGetErrorString(e);
+      g_create_error = std::string("compose_rigid_kernel is not loadable (is the gfx950 code object present?): ") + hipGetErrorString(e);
       return OFDG_EHIP;
     }
   }
@@ -328,6 +329,7 @@ void ofdg_destroy(ofdg_ctx* c) {
     drop_slot(ch.slot);
     drop_stage(ch.stage);
     ch.cov.release();
+    ch.layer.release();
     if (ch.ev_prep) (void)hipEventDestroy(ch.ev_prep);
     if (ch.ev_done) (void)hipEventDestroy(ch.ev_done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
@@ -769,6 +771,21 @@ static void bgprep_caps(const ofdg_ctx* c, int* cap_cw, int* cap_ch) {
   *cap_cw = cw; *cap_ch = ch;
 }
 
+// per-chain workspaces of a batch of n_shapes outlines and n_objects objects: coverage slots (every mode) and texture
+// layers (rigid modes).  Growing them waits for the device: every chain may be reading its own.
+static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes, size_t n_objects) {
+  const size_t plane = (size_t)c->prm.width * c->prm.height;
+  const size_t need_cov = n_shapes * 2 * plane + 16;
+  const size_t need_layer = c->prm.mode == 9 ? 0 : n_objects * 2 * plane;
+  if (need_cov <= c->chains[0].cov.cap && need_layer <= c->chains[0].layer.cap) return OFDG_OK;
+  HIP_OK(c, hipDeviceSynchronize());
+  for (int k = 0; k < c->n_chains; ++k) {
+    HIP_OK(c, c->chains[k].cov.reserve(need_cov));
+    HIP_OK(c, c->chains[k].layer.reserve(need_layer));
+  }
+  return OFDG_OK;
+}
+
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
@@ -864,16 +881,18 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
                         sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
-  {
-    static const int rgrid = std::getenv("OFDG_RASTER_GRID") ? std::atoi(std::getenv("OFDG_RASTER_GRID")) : kRasterGrid;
-    // (a caller's stream takes the coverage over with the event on raster's own packet)
-    hipExtLaunchKernelGGL(raster_kernel, dim3(rgrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
-                          ev ? ev[3] : (foreign ? ch.ev_prep : nullptr), 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
-                          box_next, n_mask_words, box_cur);
-    HIP_OK(c, hipGetLastError());
-  }
   const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
   const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
+  {
+    // rigid modes: the raster waves also render the objects' texture layers (what compose blends); mode 9 re-samples
+    // masks and textures through warp fields inside compose_deform and takes coverage slots + the pool itself
+    const LayerArgs LA{sl.d_shapes.p, sl.d_objects.p, fgpool, c->prm.mode == 9 ? nullptr : ch.layer.p, dm.fg_pitch};
+    // (a caller's stream takes the coverage over with the event on raster's own packet)
+    hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
+                          ev ? ev[3] : (foreign ? ch.ev_prep : nullptr), 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
+                          box_next, n_mask_words, box_cur, LA);
+    HIP_OK(c, hipGetLastError());
+  }
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
   // Where compose runs: on the chain's stream, right behind raster - or, if the caller passed another stream,
   // on THAT stream (in order with the caller's own work, which may still read the outputs) once the coverage
@@ -888,7 +907,6 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   const bool shared_slot = &sl != &ch.slot;
   hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
   hipEvent_t k_start = nullptr, k_stop = ev ? ev[5] : done;
-  static const bool old_compose = std::getenv("OFDG_OLD_COMPOSE") != nullptr;  // A/B: the general kernel (compose_tile) for the rigid modes too
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
@@ -897,23 +915,14 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
     hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
                           sl.d_item_count);
-  else if (!old_compose && (W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_rigid_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
-                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                          d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
-  else if (!old_compose)
-    hipExtLaunchKernelGGL(compose_rigid_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
-                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                          d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else if ((W & (W - 1)) == 0)
-    hipExtLaunchKernelGGL(compose_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+    hipExtLaunchKernelGGL(compose_rigid_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
+                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, ch.layer.p, bgpool,
+                          d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
-    // The compose kernels allocate <= 120 VGPRs -> 4 waves per SIMD; a retiring compose wave
-    // makes room for the single-wave workgroups of the latency-bound preparation kernels of
-    // the other chains, which therefore co-run with it.
-    hipExtLaunchKernelGGL(compose_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
-                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
+    hipExtLaunchKernelGGL(compose_rigid_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
+                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, ch.layer.p, bgpool,
+                          d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
     if (done) HIP_OK(c, hipEventRecord(done, CS));
@@ -1023,13 +1032,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
   {
     const int W = c->prm.width, H = c->prm.height;
-    const size_t need_cov = n_shapes * 2 * (size_t)W * H + 16;
-    if (need_cov > c->chains[0].cov.cap) {
-      HIP_OK(c, hipDeviceSynchronize());
-      for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, c->chains[k].cov.reserve(need_cov));
-    }
-    const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
-    (void)tiles;
+    { int rcw = reserve_workspaces(c, n_shapes, n_obj); if (rcw != OFDG_OK) return rcw; }
     HIP_OK(c, sl.d_items.reserve(n_shapes * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
     { int rcm = reserve_blockmask(c, sl, n_tasks); if (rcm != OFDG_OK) return rcm; }
     if (!sl.d_item_count) {
@@ -1158,11 +1161,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   HIP_OK(c, sl.d_verts.reserve(shapes_cap * 2 * kMaxVerts));
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n));
-  const size_t need_cov = shapes_cap * 2 * (size_t)W * H + 16;
-  if (need_cov > c->chains[0].cov.cap) {
-    HIP_OK(c, hipDeviceSynchronize());
-    for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, c->chains[k].cov.reserve(need_cov));
-  }
+  { int rcw = reserve_workspaces(c, shapes_cap, n_obj); if (rcw != OFDG_OK) return rcw; }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
   if (c->prm.background_prep) {
@@ -1473,7 +1472,7 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(raster_kernel, dim3(64 * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
-                     W, H, c->chains[0].cov.p, nullptr, 0, (unsigned long long*)nullptr);
+                     W, H, c->chains[0].cov.p, nullptr, 0, (unsigned long long*)nullptr, LayerArgs{nullptr, nullptr, nullptr, nullptr, 0});
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipMemcpy(coverage_host, c->chains[0].cov.p, (size_t)W * H, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));

@@ -143,24 +143,15 @@ __device__ __forceinline__ int flatten_curve3(double x1, double y1, double x2, d
 // bit k = the (dilated) box of an outline of foreground object k touches the block.  compose
 // reads its block's pair with one scalar load and visits exactly these objects.
 
-__global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
-                                                   const double* __restrict__ cs_tab, int W, int H,
-                                                   DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
-                                                   unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
-                                                   int* __restrict__ item_count, int4* __restrict__ items,
-                                                   const DevCropRef* __restrict__ crops) {
-  __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
-  __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
-  if (sf >= n_shapes * 2) return;  // wave-uniform
-  const DevShape& S = shapes[sf >> 1];
-  if (S.type == 0) return;  // unused slot of a device-sampled batch (wave-uniform)
-  const Mat M = S.m[sf & 1];
-  int2* out = verts + (size_t)sf * kMaxVerts;
-
+// The flattened outline of one (shape, frame): vertices in 24.8 fixed point written to `out` (global memory or LDS),
+// their number and bounding box (wave-reduced).  One wave; lanes = ellipse steps or path segments.
+// Reference: agg::ellipse (100 steps), conv_curve / curve3_div, ras_conv_int::upscale = iround(v * 256).
+template <class OutPtr>
+__device__ __forceinline__ int outline_verts(const DevShape& S, const Mat& M, const double* __restrict__ cs_tab, OutPtr out,
+                                             double (*stack)[kCurveMaxDepth][5], int2 (*stage)[kCurveMaxPts],
+                                             uint32_t* __restrict__ err, int lane, int& minx, int& miny, int& maxx, int& maxy) {
   int n_verts = 0;
-  int minx = 0x7FFFFFFF, miny = 0x7FFFFFFF, maxx = (int)0x80000000, maxy = (int)0x80000000;
+  minx = 0x7FFFFFFF; miny = 0x7FFFFFFF; maxx = (int)0x80000000; maxy = (int)0x80000000;
   if (S.type == 1) {
     // agg::ellipse::vertex: x = cx + cos(angle)*rx with angle = step/100 * 2*pi; the
     // cos/sin table comes from the host's libm so the doubles match the CPU's.
@@ -198,7 +189,7 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
         const int ie = (lane + 1 < n_seg) ? lane + 1 : lane;
         double x3 = (double)S.seg_x[ie], y3 = (double)S.seg_y[ie];
         xform(M, x1, y1); xform(M, x2, y2); xform(M, x3, y3);
-        cnt = flatten_curve3(x1, y1, x2, y2, x3, y3, s_stack[wave][slot], s_stage[wave][slot], kCurveMaxPts, &overflow);
+        cnt = flatten_curve3(x1, y1, x2, y2, x3, y3, stack[slot], stage[slot], kCurveMaxPts, &overflow);
       } else {
         overflow = true;
       }
@@ -214,7 +205,7 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
       minx = v0.x; maxx = v0.x; miny = v0.y; maxy = v0.y;
     } else if (cnt > 0) {
       for (int k = 0; k < cnt; ++k) {
-        const int2 v = s_stage[wave][slot][k];
+        const int2 v = stage[slot][k];
         out[off + k] = v;
         minx = min(minx, v.x); maxx = max(maxx, v.x);
         miny = min(miny, v.y); maxy = max(maxy, v.y);
@@ -223,6 +214,27 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
     if (overflow) atomicOr(err, kErrCurveCapacity);
   }
   minx = wave_min(minx); miny = wave_min(miny); maxx = wave_max(maxx); maxy = wave_max(maxy);
+  return n_verts;
+}
+
+__global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
+                                                   const double* __restrict__ cs_tab, int W, int H,
+                                                   DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
+                                                   unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
+                                                   int* __restrict__ item_count, int4* __restrict__ items,
+                                                   const DevCropRef* __restrict__ crops) {
+  __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
+  __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
+  if (sf >= n_shapes * 2) return;  // wave-uniform
+  const DevShape& S = shapes[sf >> 1];
+  if (S.type == 0) return;  // unused slot of a device-sampled batch (wave-uniform)
+  const Mat M = S.m[sf & 1];
+  int2* out = verts + (size_t)sf * kMaxVerts;
+
+  int minx, miny, maxx, maxy;
+  int n_verts = outline_verts(S, M, cs_tab, out, s_stack[wave], s_stage[wave], err, lane, minx, miny, maxx, maxy);
   // AGG dx_limit: an edge spanning >= 16384 px takes a different code path in
   // rasterizer_cells_aa::line; blueprints never get close, flag it if one does.
   if (n_verts > 0 && ((long long)maxx - (long long)minx >= (16384LL << 8))) {
@@ -511,125 +523,120 @@ struct ChunkCells {
   int carry[kBandRows];
 };
 
-// One WAVE per item (no workgroup barriers): clear its cells, accumulate every
-// (edge, scanline) pair of the outline that can reach the chunk, sweep, store.
-// What raster_kernel needs to render an outline's texture layer (rigid modes): see layer_pass below.
-struct LayerArgs {
-  const DevShape* shapes;
-  const DevObject* objects;
-  const uint32_t* pool;   // foreground textures
-  uint32_t* layer;        // [object][frame][H][W] dwords: B | G << 8 | R << 16 | coverage << 24; nullptr: no layers (mode 9)
-  int fg_pitch;
+// LDS of one rasterising wave
+struct RasterWs {
+  ChunkCells cells;
+  int queue[64 * kBandRows];
 };
-__device__ __forceinline__ void layer_pass(const LayerArgs& A, int sf, int by0, int rows, int X0, int X1, int W, int H,
-                                           unsigned long long nz, const uint8_t (*alpha)[kChunkW], int lane);
 
+// One item = one outline x one band of kBandRows scanlines x the padded column range [X0, X1], by ONE wave (no
+// workgroup barriers): clear its cells, accumulate every (edge, scanline) pair of the outline that can reach the
+// chunk, sweep, store the coverage bytes, mark the block masks.  v: the outline's nv vertices; F*: its pixel box.
+__device__ __forceinline__ void raster_item(RasterWs& ws, const int2* __restrict__ v, int nv, int Fx0, int Fy0, int Fx1, int Fy1, int sf,
+                                            int band, int X0, int X1, int W, int H, uint8_t* __restrict__ cov,
+                                            unsigned long long* __restrict__ blockmask, int sample, int obj_local, int lane) {
+  ChunkCells& tc = ws.cells;
+  const int by0 = band * kBandRows;
+  const int rows = min(kBandRows, H - by0);
+  const bool has_edges = (Fx0 <= Fx1) && (by0 <= Fy1) && (by0 + kBandRows - 1 >= Fy0) && (Fx0 <= X1) && (Fx1 >= X0);
+  uint8_t* dst = cov + ((size_t)sf * H + by0) * W + X0;
+  const int c2 = 2 * lane;  // this lane's two columns of the chunk
+  const bool in_range = (X0 + c2) <= X1;  // X0 is even and X1 odd (tile-aligned, W % 4 == 0)
+  if (!has_edges) {
+    if (in_range)
+      for (int r = 0; r < rows; ++r) *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = 0;
+    return;
+  }
+  {  // clear
+    int4* z = reinterpret_cast<int4*>(&tc);
+    const int n16 = (2 * kBandRows * kChunkW) / 4;
+    for (int i = lane; i < n16; i += 64) z[i] = make_int4(0, 0, 0, 0);
+    if (lane < kBandRows) tc.carry[lane] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  ChunkAcc acc;
+  acc.cover = &tc.cover[0][0]; acc.area = &tc.area[0][0]; acc.carry = &tc.carry[0];
+  acc.X0 = X0; acc.X1 = X1;
+  // Lane = edge: find the scanlines of the band each edge crosses, compact the
+  // (edge, scanline) pairs that can reach the chunk into a dense queue, then let
+  // all 64 lanes work on real pairs.  The closing edge (last -> first) is edge nv-1.
+  int* queue = ws.queue;
+  for (int e0 = 0; e0 < nv; e0 += 64) {
+    const int e = e0 + lane;
+    int n_rows = 0, rlo = 0;
+    if (e < nv) {
+      const int2 a = v[e];
+      const int2 b = v[(e + 1 == nv) ? 0 : e + 1];
+      const int eya = a.y >> 8, eyb = b.y >> 8;
+      rlo = max(min(eya, eyb), by0);
+      const int rhi = min(max(eya, eyb), by0 + rows - 1);
+      if (rhi >= rlo && (min(a.x, b.x) >> 8) <= X1 && a.y != b.y) n_rows = rhi - rlo + 1;
+    }
+    const int incl = wave_scan_incl(n_rows);
+    const int total = __shfl(incl, 63, 64);
+    int at = incl - n_rows;
+    for (int k = 0; k < n_rows; ++k) queue[at++] = (e << 4) | (rlo + k - by0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int q0 = 0; q0 < total; q0 += 64) {
+      const int q = q0 + lane;
+      if (q < total) {
+        const int code = queue[q];
+        const int ee = code >> 4, r = code & 15;
+        const int2 a = v[ee];
+        const int2 b = v[(ee + 1 == nv) ? 0 : ee + 1];
+        edge_scanline(acc, r, by0 + r, a.x, a.y, b.x, b.y);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  // sweep: lane l owns columns 2l, 2l+1 of every row
+  int nonzero = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int2 cv = *reinterpret_cast<const int2*>(&tc.cover[r][c2]);
+    const int2 ar = *reinterpret_cast<const int2*>(&tc.area[r][c2]);
+    const int s2 = cv.x + cv.y;
+    const int base = tc.carry[r] + wave_scan_incl(s2) - s2;
+    int a0 = ((base + cv.x) << 9) - ar.x, a1 = ((base + s2) << 9) - ar.y;  // calculate_alpha (shift 9)
+    a0 >>= 9; a1 >>= 9;
+    a0 = a0 < 0 ? -a0 : a0; a1 = a1 < 0 ? -a1 : a1;
+    a0 = a0 > 255 ? 255 : a0; a1 = a1 > 255 ? 255 : a1;
+    if (in_range) { *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = (uint16_t)(a0 | (a1 << 8)); nonzero |= a0 | a1; }
+  }
+  // lanes 0-31 hold the left 64 x 8 block of the chunk, lanes 32-63 the right one
+  const unsigned long long nz = __ballot(nonzero != 0);
+  if (blockmask) {
+    // compose visits an object in a 64 x 8 block only if its outline has coverage there
+    const int half = lane >> 5;
+    if ((lane & 31) == 0 && ((nz >> (32 * half)) & 0xFFFFFFFFull)) {
+      const int nbx = (W + kTileW - 1) / kTileW, nby = (H + kBandRows - 1) / kBandRows;
+      atomicOr(blockmask + ((size_t)(sample * nby + band) * nbx + (X0 / kTileW + half)) * 2 + (sf & 1), 1ull << obj_local);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the next item's clear
+}
+
+// raster_kernel: persistent single-wave workgroups walk geom_kernel's item list.
 __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShapeFrame* __restrict__ frames,
                                                      const int4* __restrict__ items,
                                                      const int* __restrict__ item_count,
                                                      const int2* __restrict__ verts, int W, int H,
                                                      uint8_t* __restrict__ cov,
                                                      unsigned long long* __restrict__ blockmask_next, int n_mask_words,
-                                                     unsigned long long* __restrict__ blockmask, LayerArgs LA) {
-  __shared__ __attribute__((aligned(16))) ChunkCells s_cells[kRasterWaves];
-  __shared__ int s_queue[kRasterWaves][64 * kBandRows];
-  __shared__ __attribute__((aligned(4))) uint8_t s_alpha[kRasterWaves][kBandRows][kChunkW];
+                                                     unsigned long long* __restrict__ blockmask) {
+  __shared__ __attribute__((aligned(16))) RasterWs s_ws[kRasterWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // clear the block masks the NEXT launch of this slot accumulates into (the other parity)
   for (int gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_mask_words; gid += gridDim.x * blockDim.x) blockmask_next[gid] = 0ull;
-  ChunkCells& tc = s_cells[wave];
   const int n_items = *item_count;
   const int n_waves = gridDim.x * kRasterWaves;
   for (int it = blockIdx.x * kRasterWaves + wave; it < n_items; it += n_waves) {
     const int4 item = items[it];
-    const int sf = __builtin_amdgcn_readfirstlane(item.x);
-    const int by0 = __builtin_amdgcn_readfirstlane(item.y) * kBandRows;
+    const int sf = __builtin_amdgcn_readfirstlane(item.x), band = __builtin_amdgcn_readfirstlane(item.y);
     const int X0 = __builtin_amdgcn_readfirstlane(item.z), X1 = __builtin_amdgcn_readfirstlane(item.w);
     const DevShapeFrame F = frames[sf];
-    const int rows = min(kBandRows, H - by0);
-    const bool has_edges = (F.x0 <= F.x1) && (by0 <= F.y1) && (by0 + kBandRows - 1 >= F.y0) && (F.x0 <= X1) && (F.x1 >= X0);
-    uint8_t* dst = cov + ((size_t)sf * H + by0) * W + X0;
-    const int c2 = 2 * lane;  // this lane's two columns of the chunk
-    const bool in_range = (X0 + c2) <= X1;  // X0 is even and X1 odd (tile-aligned, W % 4 == 0)
-    if (!has_edges) {
-      if (in_range)
-        for (int r = 0; r < rows; ++r) *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = 0;
-      continue;
-    }
-    {  // clear
-      int4* z = reinterpret_cast<int4*>(&tc);
-      const int n16 = (2 * kBandRows * kChunkW) / 4;
-      for (int i = lane; i < n16; i += 64) z[i] = make_int4(0, 0, 0, 0);
-      if (lane < kBandRows) tc.carry[lane] = 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    ChunkAcc acc;
-    acc.cover = &tc.cover[0][0]; acc.area = &tc.area[0][0]; acc.carry = &tc.carry[0];
-    acc.X0 = X0; acc.X1 = X1;
-    const int nv = F.n_verts;
-    const int2* v = verts + (size_t)sf * kMaxVerts;
-    // Lane = edge: find the scanlines of the band each edge crosses, compact the
-    // (edge, scanline) pairs that can reach the chunk into a dense queue, then let
-    // all 64 lanes work on real pairs.  The closing edge (last -> first) is edge nv-1.
-    int* queue = s_queue[wave];
-    for (int e0 = 0; e0 < nv; e0 += 64) {
-      const int e = e0 + lane;
-      int n_rows = 0, rlo = 0;
-      if (e < nv) {
-        const int2 a = v[e];
-        const int2 b = v[(e + 1 == nv) ? 0 : e + 1];
-        const int eya = a.y >> 8, eyb = b.y >> 8;
-        rlo = max(min(eya, eyb), by0);
-        const int rhi = min(max(eya, eyb), by0 + rows - 1);
-        if (rhi >= rlo && (min(a.x, b.x) >> 8) <= X1 && a.y != b.y) n_rows = rhi - rlo + 1;
-      }
-      const int incl = wave_scan_incl(n_rows);
-      const int total = __shfl(incl, 63, 64);
-      int at = incl - n_rows;
-      for (int k = 0; k < n_rows; ++k) queue[at++] = (e << 4) | (rlo + k - by0);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      for (int q0 = 0; q0 < total; q0 += 64) {
-        const int q = q0 + lane;
-        if (q < total) {
-          const int code = queue[q];
-          const int ee = code >> 4, r = code & 15;
-          const int2 a = v[ee];
-          const int2 b = v[(ee + 1 == nv) ? 0 : ee + 1];
-          edge_scanline(acc, r, by0 + r, a.x, a.y, b.x, b.y);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    // sweep: lane l owns columns 2l, 2l+1 of every row
-    int nonzero = 0;
-    for (int r = 0; r < rows; ++r) {
-      const int2 cv = *reinterpret_cast<const int2*>(&tc.cover[r][c2]);
-      const int2 ar = *reinterpret_cast<const int2*>(&tc.area[r][c2]);
-      const int s2 = cv.x + cv.y;
-      const int base = tc.carry[r] + wave_scan_incl(s2) - s2;
-      int a0 = ((base + cv.x) << 9) - ar.x, a1 = ((base + s2) << 9) - ar.y;  // calculate_alpha (shift 9)
-      a0 >>= 9; a1 >>= 9;
-      a0 = a0 < 0 ? -a0 : a0; a1 = a1 < 0 ? -a1 : a1;
-      a0 = a0 > 255 ? 255 : a0; a1 = a1 > 255 ? 255 : a1;
-      if (in_range) { *reinterpret_cast<uint16_t*>(dst + (size_t)r * W + c2) = (uint16_t)(a0 | (a1 << 8)); nonzero |= a0 | a1; }
-      *reinterpret_cast<uint16_t*>(&s_alpha[wave][r][c2]) = in_range ? (uint16_t)(a0 | (a1 << 8)) : (uint16_t)0;
-    }
-    // lanes 0-31 hold the left 64 x 8 block of the chunk, lanes 32-63 the right one
-    const unsigned long long nz = __ballot(nonzero != 0);
-    if (LA.layer) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      layer_pass(LA, sf, by0, rows, X0, X1, W, H, nz, s_alpha[wave], lane);
-    }
-    if (blockmask) {
-      // compose visits an object in a 64 x 8 block only if its outline has coverage there
-      const int half = lane >> 5;
-      if ((lane & 31) == 0 && ((nz >> (32 * half)) & 0xFFFFFFFFull)) {
-        const int nbx = (W + kTileW - 1) / kTileW, nby = (H + kBandRows - 1) / kBandRows;
-        atomicOr(blockmask + ((size_t)(F.pad[0] * nby + item.y) * nbx + (X0 / kTileW + half)) * 2 + (sf & 1), 1ull << F.pad[1]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the next item's clear
+    raster_item(s_ws[wave], verts + (size_t)sf * kMaxVerts, F.n_verts, F.x0, F.y0, F.x1, F.y1, sf, band, X0, X1, W, H, cov, blockmask,
+                F.pad[0], F.pad[1], lane);
   }
 }
 
@@ -1292,7 +1299,7 @@ __global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
 }
 
 // --------------------------------------------------------------------------
-// Load helpers of the rigid-mode kernels (compose_rigid, raster_kernel's layer pass)
+// Load helpers of the rigid-mode compose kernels
 // --------------------------------------------------------------------------
 // a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
 template <class T>
@@ -1394,133 +1401,25 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
   }
 }
 
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) const u32x4_t g_uint4;
-__device__ __forceinline__ uint4 gload4(const char* base, uint32_t off) {
-  asm("" : "+v"(off));
-  const u32x4_t v = *(g_uint4*)((g_char*)base + off);
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// span_image_filter_rgb_bilinear for ONE pixel per lane (any row length): paired 8-byte tap loads while every lane
-// that needs a result stays inside the texture, the general interpolator (reflection) otherwise.
-__device__ __forceinline__ uint32_t sample1(const uint32_t* __restrict__ tex_, const WarpGeom& g, const RowDDA& R, int i, bool need) {
-  const uint32_t* __restrict__ tex = uniform_ptr(tex_);
-  const int xh = dda_at(R.x1, R.lx, R.rx, g.tw, g.nshift, i) - 128;
-  const int yh = dda_at(R.y1, R.ly, R.ry, g.tw, g.nshift, i) - 128;
-  const bool in_range = (unsigned)(xh >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(yh >> 8) <= (unsigned)(g.th - 2);
-  if (__ballot(need && !in_range) == 0ull) {
-    const char* base = reinterpret_cast<const char*>(tex);
-    const char* base1 = uniform_ptr(base + (size_t)g.pitch * 4u);
-    const uint32_t off = need ? ((uint32_t)(yh >> 8) * (uint32_t)g.pitch + (uint32_t)(xh >> 8)) * 4u : 0u;
-    const uint2 t0 = gload2(base, off), t1 = gload2(base1, off);
-    return bilerp_rgb(t0, t1, (uint32_t)xh & 255u, (uint32_t)yh & 255u);
-  }
-  return need ? sample_bilinear(tex, g, R, i) : 0u;
-}
-
-// The texture layer of one raster item (one outline, 8 scanlines, up to 128 columns), rigid modes: for every 64 x 8
-// block in which the outline has coverage, the object's texture under the frame's warp - frame 0: the crop itself
-// (identity, DG:339-340), frame 1: getTransformedTexture through the inverse motion (DG:168-231) - packed with the raw
-// coverage byte, one dword per pixel.  compose then reads an object's block as aligned 16-byte loads instead of
-// gathering a rotated window inside its store stream; here a tap instruction covers an 8 x 8 pixel block (lane = pixel),
-// whose window is a dozen texture lines whatever the rotation.
-//   simple object: every pixel of the block is written (0 where the outline has no coverage): compose takes masks AND
-//                  texels from the layer;
-//   component of a composite: only the texels under this component's coverage are written, into the composite's layer
-//                  (a composite's mask is non-zero only where an additive component has coverage); compose builds the
-//                  mask from the components' coverage slots as before.
-__device__ __forceinline__ void layer_pass(const LayerArgs& A, int sf, int by0, int rows, int X0, int X1, int W, int H,
-                                           unsigned long long nz, const uint8_t (*alpha)[kChunkW], int lane) {
-  const int obj = __builtin_amdgcn_readfirstlane(A.shapes[sf >> 1].object);
-  const DevObject& O = A.objects[obj];
-  const bool simple = O.kind == 1;
-  const uint32_t* tex = A.pool + O.tex_base;
-  uint32_t* L = A.layer + ((size_t)obj * 2 + (sf & 1)) * ((size_t)W * H);
-  const int r = lane >> 3, cx = lane & 7;
-  const int y = by0 + r;
-  WarpGeom g;
-  g.tw = W; g.th = H; g.tw2 = 2 * W; g.th2 = 2 * H;
-  g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
-  g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
-  g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
-  g.pitch = A.fg_pitch;
-  RowDDA R = RowDDA();
-  if (sf & 1) R = make_row(O.tex_inv, min(y, H - 1), W, g.nshift);
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (X0 + 64 * half > X1) break;
-    if (!((nz >> (32 * half)) & 0xFFFFFFFFull)) continue;  // no coverage in this 64 x 8 block: compose never reads it
-    // the eight 8 x 8 sub-blocks of the block: every load goes out before the first is consumed
-    uint32_t a8[8];     // coverage byte | x fraction << 8 | y fraction << 16
-    uint2 t0[8], t1[8];
-    bool fast = true;   // frame 1: every tap of every pixel with coverage lies inside the texture
-    int xh[8], yh[8];
-    unsigned long long any8 = 0;
-#pragma unroll
-    for (int sb = 0; sb < 8; ++sb) {
-      const int col = 64 * half + 8 * sb + cx;
-      a8[sb] = (r < rows) ? (uint32_t)alpha[r][col] : 0u;
-      if (__ballot(a8[sb] != 0u)) any8 |= 1ull << sb;
-      if (sf & 1) {
-        xh[sb] = dda_at(R.x1, R.lx, R.rx, g.tw, g.nshift, X0 + col) - 128;
-        yh[sb] = dda_at(R.y1, R.ly, R.ry, g.tw, g.nshift, X0 + col) - 128;
-        const bool in_range = (unsigned)(xh[sb] >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(yh[sb] >> 8) <= (unsigned)(g.th - 2);
-        fast = fast && (a8[sb] == 0u || in_range);
-      }
-    }
-    fast = __ballot(!fast) == 0ull;
-    const char* base = reinterpret_cast<const char*>(uniform_ptr(tex));
-    const char* base1 = uniform_ptr(base + (size_t)g.pitch * 4u);
-    if (!(sf & 1)) {
-#pragma unroll
-      for (int sb = 0; sb < 8; ++sb) {
-        t0[sb] = make_uint2(0, 0);
-        if ((any8 >> sb) & 1ull) t0[sb].x = gload1(base, a8[sb] ? (uint32_t)(y * g.pitch + X0 + 64 * half + 8 * sb + cx) * 4u : 0u);
-      }
-    } else if (fast) {
-#pragma unroll
-      for (int sb = 0; sb < 8; ++sb) {
-        t0[sb] = make_uint2(0, 0); t1[sb] = make_uint2(0, 0);
-        if ((any8 >> sb) & 1ull) {
-          const uint32_t off = a8[sb] ? ((uint32_t)(yh[sb] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[sb] >> 8)) * 4u : 0u;
-          t0[sb] = gload2(base, off); t1[sb] = gload2(base1, off);
-        }
-      }
-    }
-#pragma unroll
-    for (int sb = 0; sb < 8; ++sb) {
-      const int x = X0 + 64 * half + 8 * sb + cx;
-      const bool need = a8[sb] != 0u;
-      uint32_t t = 0;
-      if ((any8 >> sb) & 1ull) {
-        if (!(sf & 1)) t = t0[sb].x;
-        else if (fast) t = bilerp_rgb(t0[sb], t1[sb], (uint32_t)xh[sb] & 255u, (uint32_t)yh[sb] & 255u);
-        else t = need ? sample_bilinear(tex, g, R, x) : 0u;
-      }
-      const uint32_t v = need ? ((t & 0x00FFFFFFu) | (a8[sb] << 24)) : 0u;
-      if (r < rows && x <= X1 && (simple || need)) L[(size_t)y * W + x] = v;
-    }
-  }
-}
-
 // --------------------------------------------------------------------------
-// compose_rigid_kernel: the compose kernel of the rigid modes (every mode but 9).  A strip's wave reads, per object
-// of its block, ONE aligned 16-byte load per frame from the object's texture layer (raster_kernel: texel + coverage
-// byte per pixel) - addressed by nothing but the block's object mask, so the loads of the next object are in flight
-// while the current one is blended - and gathers only the background's frame-1 taps itself.
-//   scalar stage     sample record (background matrices inline) + the block's object masks   [kernel arguments are
+// compose_rigid_kernel: the compose kernel of the rigid modes (every mode but 9), written around the
+// latency of a strip: what a wave waits for is fetched in as few dependent round trips as the data allows.
+//   scalar stage 1   sample record (background matrices inline) + the block's object masks   [kernel arguments are
 //                    preloaded into SGPRs: leading scalar parameters, -amdgpu-kernarg-preload-count]
-//   vector stage     background texels of both frames, layer dwords + record of the first object of the mask
-//   per visit        (loads of the following object go out) masks from the coverage bytes, blends, flow of the owner
+//   scalar stage 2   headers (coverage slot, texture origin, kind) of the first kPre objects of the mask
+//   vector stage 1   background texels of both frames, coverage of those objects, their full records (lane i reads
+//                    dword i; the matrices are moved to SGPRs with v_readlane when the visit needs them)
+//   per visit        texture taps of both frames (one round trip), blend, flow
 //   stores           8 fp32 planes, 16-byte non-temporal stores
 // Same arithmetic as compose_tile (the mode-9 kernels), bit for bit.
 // --------------------------------------------------------------------------
+constexpr int kPre = 2;  // objects of a block whose header / coverage / record are fetched ahead of their visit
+
 template <bool kPow2>
 __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
                                               const DevObject* __restrict__ objects, const uint8_t* __restrict__ cov,
-                                              int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch,
-                                              const uint32_t* __restrict__ layer, const uint32_t* __restrict__ bgpool,
+                                              int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+                                              const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
                                               float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
                                               const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
   static_assert(kPx == 4, "mask bytes are packed four to a word");
@@ -1542,7 +1441,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   const int y = ty0 + sub * 4 + (lane >> 4);
   const bool inside = (x0 < W) && (y < H);
 
-  // ---- scalar stage: sample (+ background) record and block masks, requested in ONE batch ----
+  // ---- scalar stage 1: sample (+ background) record and block masks, requested in ONE batch ----
   // (the compiler loads a struct field where its first use is; an empty asm statement that names every value right here
   //  makes that one place: one s_waitcnt for the whole record instead of one per use site)
   struct SmpRec { int first_object, first_shape; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; } smp;
@@ -1564,38 +1463,28 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   unsigned long long omask = mask0 | mask1;
   const DevObject* objs = objects + smp.first_object;
   const uint32_t pix = (uint32_t)(y * W + x0);
-  const size_t plane = (size_t)W * H;
+  const size_t slot_bytes = (size_t)W * H;
 
-  // outline slot of foreground object oi (>= 1) relative to the sample's first; bit 15: composite (scalar-cache hits:
-  // the table is part of the sample record)
+  // ---- scalar stage 2: outline slots of the first kPre objects of the mask (sample record: scalar-cache hits) ----
   const uint32_t* shape_tab = reinterpret_cast<const uint32_t*>(samples[s].shape_of);
-  auto shape_entry = [&](int oi) -> uint32_t {  // two 16-bit entries per dword
+  auto shape_entry = [&](int oi) -> uint32_t {  // oi >= 1; two 16-bit entries per dword
     const uint32_t w = shape_tab[(oi - 1) >> 1];
     return ((oi - 1) & 1) ? (w >> 16) : (w & 0xFFFFu);
   };
-  // What a visit consumes, requested one visit ahead: the object's layer dwords of both frames (texel | coverage << 24),
-  // its record (lane i holds dword i: the motion matrix is moved to SGPRs with v_readlane when a pixel changes owner)
-  // and its outline-table entry.  The addresses depend on the block's mask and the sample record only.
-  struct Visit { int oi; uint32_t sh, rec; uint4 l0, l1; };
-  auto request = [&](int oi) {
-    Visit v;
-    v.oi = oi; v.sh = (uint32_t)kShapeComposite; v.rec = 0;
-    v.l0 = make_uint4(0, 0, 0, 0); v.l1 = make_uint4(0, 0, 0, 0);
-    if (oi) {  // (wave-uniform)
-      v.sh = shape_entry(oi);
-      const char* L = reinterpret_cast<const char*>(uniform_ptr(layer + (size_t)(smp.first_object + oi) * 2 * plane));
-      const char* L1 = reinterpret_cast<const char*>(uniform_ptr(layer + ((size_t)(smp.first_object + oi) * 2 + 1) * plane));
-      const uint32_t off = inside ? pix * 4u : 0u;
-      if ((mask0 >> (oi - 1)) & 1ull) v.l0 = gload4(L, off);
-      if ((mask1 >> (oi - 1)) & 1ull) v.l1 = gload4(L1, off);
-      v.rec = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 11)];  // motion
+  int pre_oi[kPre];
+  uint32_t pre_sh[kPre];
+  {
+    unsigned long long m = omask;
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      pre_oi[k] = m ? __ffsll((long long)m) : 0;
+      m &= m - 1;  // (0 stays 0)
+      pre_sh[k] = pre_oi[k] ? shape_entry(pre_oi[k]) : (uint32_t)kShapeComposite;
     }
-    return v;
-  };
-  auto next_object = [&]() { const int oi = omask ? __ffsll((long long)omask) : 0; omask &= omask - 1; return oi; };  // (0 stays 0)
+  }
 
-  // ---- vector stage: EVERY load the wave knows how to address goes out before anything is waited for: background
-  // taps of frame 1, background texels of frame 0, the first object's layer dwords and record.  Lanes outside the frame
+  // ---- vector stage 1: EVERY load the wave knows how to address goes out before anything is waited for: background
+  // taps of frame 1, background texels of frame 0, coverage + records of the first kPre objects.  Lanes outside the frame
   // (W, H not multiples of the strip) read the texel at the origin instead of branching around the loads. ----
   WarpGeom gb;
   gb.tw = 2 * W; gb.th = 2 * H; gb.tw2 = 4 * W; gb.th2 = 4 * H;
@@ -1610,8 +1499,26 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   Taps4 Tb;
   Rb = make_row<kPow2>(smp.bg_tex_inv, inside ? yy : H / 2, gb.tw, gb.nshift);
   if constexpr (kPow2) Tb = taps_issue(btex, gb, Rb, xx, inside);
-  bq = gload4(reinterpret_cast<const char*>(btex), inside ? (uint32_t)(yy * gb.pitch + xx) * 4u : 0u);  // frame 0: identity warp == copy (DG:667-668, 680)
-  Visit nxt = request(next_object());
+  {
+    uint32_t boff = inside ? (uint32_t)(yy * gb.pitch + xx) * 4u : 0u;
+    asm("" : "+v"(boff));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = *(__attribute__((address_space(1))) const u32x4_t*)((g_char*)reinterpret_cast<const char*>(btex) + boff);  // frame 0: identity warp == copy (DG:667-668, 680)
+    bq = make_uint4(v.x, v.y, v.z, v.w);
+  }
+  uint32_t pre_c0[kPre], pre_c1[kPre], pre_rec[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    pre_c0[k] = 0; pre_c1[k] = 0; pre_rec[k] = 0;
+    if (!(pre_sh[k] & kShapeComposite)) {  // a simple object (wave-uniform)
+      const uint8_t* c = cov + (size_t)(smp.first_shape + (int)pre_sh[k]) * 2 * slot_bytes;
+      if (inside) {
+        if ((mask0 >> (pre_oi[k] - 1)) & 1ull) pre_c0[k] = *reinterpret_cast<const uint32_t*>(c + pix);
+        if ((mask1 >> (pre_oi[k] - 1)) & 1ull) pre_c1[k] = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+      }
+      pre_rec[k] = reinterpret_cast<const uint32_t*>(&objs[pre_oi[k]])[min(lane, 25)];  // motion, tex_inv, tex_base
+    }
+  }
 
   // ---- background: frames start as its textures (masks are all 255), flow of every pixel ----
   uint32_t px0[kPx], px1[kPx];
@@ -1642,23 +1549,44 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   }
 
   // ---- foreground objects in z-order ----
-  while (nxt.oi) {
-    const Visit cur = nxt;
-    nxt = request(next_object());  // the following object's loads are in flight while this one is blended
-    const int oi = cur.oi;
+  WarpGeom g;
+  g.tw = W; g.th = H; g.tw2 = 2 * W; g.th2 = 2 * H;
+  g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
+  g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
+  g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
+  g.pitch = fg_pitch;
+  int vi = 0;  // visit number
+  while (omask) {
+    const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
+    omask &= omask - 1;
     const bool has0 = (mask0 >> (oi - 1)) & 1ull, has1 = (mask1 >> (oi - 1)) & 1ull;  // wave-uniform
     // (opaque copies: the int -> double conversions of the pixel coordinates are redone per visit instead of being
     //  hoisted out of the loop, where they would hold two dozen registers across every visit)
     int xv = x0, yv = y;
     asm volatile("" : "+v"(xv), "+v"(yv));
-    const uint32_t l0[4] = {cur.l0.x, cur.l0.y, cur.l0.z, cur.l0.w}, l1[4] = {cur.l1.x, cur.l1.y, cur.l1.z, cur.l1.w};
+    uint32_t sh, c0w = 0, c1w = 0, recw = 0;
+    if (vi < kPre) {
+      sh = vi == 0 ? pre_sh[0] : pre_sh[kPre - 1];
+      c0w = vi == 0 ? pre_c0[0] : pre_c0[kPre - 1];
+      c1w = vi == 0 ? pre_c1[0] : pre_c1[kPre - 1];
+      recw = vi == 0 ? pre_rec[0] : pre_rec[kPre - 1];
+    } else {
+      sh = shape_entry(oi);
+      if (!(sh & kShapeComposite)) {
+        const uint8_t* c = cov + (size_t)(smp.first_shape + (int)sh) * 2 * slot_bytes;
+        if (inside) {
+          if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
+          if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
+        }
+        recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
+      }
+    }
+    ++vi;
+    static_assert(kPre == 2 || kPre == 1, "the selects above pick between two prefetched sets");
 
     uint32_t m0w, m1w, n0w;  // blending masks of the two frames and the thresholded frame-0 mask, byte p = pixel p
-    if (!(cur.sh & kShapeComposite)) {
-      // raw coverage of the outline: the layer's top bytes (0 outside the frame: those lanes loaded nothing they use)
-      const uint32_t c0w = inside ? ((l0[0] >> 24) | ((l0[1] >> 24) << 8) | ((l0[2] >> 24) << 16) | (l0[3] & 0xFF000000u)) : 0u;
-      const uint32_t c1w = inside ? ((l1[0] >> 24) | ((l1[1] >> 24) << 8) | ((l1[2] >> 24) << 16) | (l1[3] & 0xFF000000u)) : 0u;
-      // the block has coverage but none of it under this strip's pixels: nothing to mask or blend
+    if (!(sh & kShapeComposite)) {
+      // the box touches the block but the outline covers none of this strip's pixels: nothing to mask, sample or blend
       if (__ballot((c0w | c1w) != 0u) == 0ull) continue;
       m0w = 0; m1w = 0; n0w = 0;
 #pragma unroll
@@ -1670,13 +1598,13 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
         m1w |= (uint32_t)(use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0)) << (8 * p);
       }
     } else {
-      // composite: sequential fp32 add / subtract over the components' coverage (DG:591-646)
+      // composite: sequential fp32 add / subtract over the components (DG:591-646)
       const DevObjectHdr h = *reinterpret_cast<const DevObjectHdr*>(&objs[oi].tex_base);
       int ua0[kPx], ua1[kPx], un1[kPx], na0[kPx];
 #pragma unroll
       for (int p = 0; p < kPx; ++p) { ua0[p] = ua1[p] = un1[p] = 0; na0[p] = 0; }
       for (int k = 0; k < h.n_shapes; ++k) {
-        const uint8_t* c = cov + (size_t)(h.first_shape + k) * 2 * plane;
+        const uint8_t* c = cov + (size_t)(h.first_shape + k) * 2 * slot_bytes;
         uint32_t k0w = 0, k1w = 0;
         if (inside) {
           // a component's coverage exists only in the 64 x 8 blocks its own box touches
@@ -1685,7 +1613,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
           const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
           const bool v1 = F1.x0 <= F1.x1 && F1.x0 <= tx0 + kTileW - 1 && F1.x1 >= tx0 && F1.y0 <= by0c + kBandRows - 1 && F1.y1 >= by0c;
           if (has0 && v0) k0w = *reinterpret_cast<const uint32_t*>(c + pix);
-          if (has1 && v1) k1w = *reinterpret_cast<const uint32_t*>(c + plane + pix);
+          if (has1 && v1) k1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
         }
         const bool additive = (h.additive >> k) & 1u;
 #pragma unroll
@@ -1710,21 +1638,38 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
         n0w |= (uint32_t)na0[p] << (8 * p);
       }
       if (__ballot((m0w | m1w | n0w) != 0u) == 0ull) continue;
+      recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
     }
 
-    // CImg draw_image of the object's textures (frame 1: getTransformedTexture, frame 0: the crop itself) - the layer's
-    // low 24 bits; a mask byte of 0 leaves the pixel as it is
+    // the object's matrices: dword i of the record sits in lane i
+    auto rec_double = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane((int)recw, 2 * i + 1), __builtin_amdgcn_readlane((int)recw, 2 * i)); };
+    // origin of the W x H centre crop: dwords 24, 25 of the record
+    const uint32_t* tex = pool + (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)recw, 25) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)recw, 24));
+    // frame 0 texture: identity warp == the crop itself (DG:339-340); issued with the frame-1 taps: one round trip
+    uint4 q0 = make_uint4(0, 0, 0, 0);
+    if (m0w) q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yv * g.pitch + xv));
     if (__ballot(m1w != 0u)) {
+      Mat ti;
+      ti.sx = rec_double(6); ti.shy = rec_double(7); ti.shx = rec_double(8); ti.sy = rec_double(9); ti.tx = rec_double(10); ti.ty = rec_double(11);
+      const RowDDA R = make_row<kPow2>(ti, yv, W, g.nshift);
+      uint32_t t1[kPx];
+      if constexpr (kPow2) {
+        const Taps4 T = taps_issue(tex, g, R, xv, m1w != 0u);
+        taps_finish(T, t1);
+      } else {
 #pragma unroll
-      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], l1[p] & 0x00FFFFFFu, (m1w >> (8 * p)) & 255u);
+        for (int p = 0; p < kPx; ++p) t1[p] = m1w ? sample_bilinear(tex, g, R, xv + p) : 0u;
+      }
+#pragma unroll
+      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (m1w >> (8 * p)) & 255u);  // m == 0 leaves the pixel as is
     }
-    if (__ballot(m0w != 0u)) {
+    if (m0w) {
+      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
-      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], l0[p] & 0x00FFFFFFu, (m0w >> (8 * p)) & 255u);
+      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (m0w >> (8 * p)) & 255u);
     }
     if (__ballot(n0w != 0u)) {
-      // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns; dword i of the record sits in lane i
-      auto rec_double = [&](int i) { return __hiloint2double(__builtin_amdgcn_readlane((int)cur.rec, 2 * i + 1), __builtin_amdgcn_readlane((int)cur.rec, 2 * i)); };
+      // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns
       Mat mo;
       mo.sx = rec_double(0); mo.shy = rec_double(1); mo.shx = rec_double(2); mo.sy = rec_double(3); mo.tx = rec_double(4); mo.ty = rec_double(5);
 #pragma unroll
@@ -1745,6 +1690,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   // (SGPR pair) + one 32-bit byte offset per lane; the offset is made opaque so that no address arithmetic is
   // hoisted above the object loop (it would hold registers there).
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const size_t plane = (size_t)W * H;
   uint32_t ob = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 4u;
   asm volatile("" : "+v"(ob));
   char* b0 = reinterpret_cast<char*>(img0 + (size_t)s * 3 * plane);
@@ -1768,22 +1714,21 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
 // Leading scalar parameters are preloaded into SGPRs (no load, no wait before the first record fetch).
 __global__ __launch_bounds__(64) void compose_rigid_kernel(
     const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch,
-    const uint32_t* __restrict__ layer, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
+    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
     float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_rigid<false>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, layer, bgpool, img0, img1,
+  compose_rigid<false>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
                        flow, frames, item_count);
 }
-// W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads for the background.
+// W a power of two (512, 1024, ...): shift-only interpolators and paired tap loads.
 __global__ __launch_bounds__(64) void compose_rigid_pow2_kernel(
     const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch,
-    const uint32_t* __restrict__ layer, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
+    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
+    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
     float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
-  compose_rigid<true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, layer, bgpool, img0, img1,
+  compose_rigid<true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
                       flow, frames, item_count);
 }
-
 
 // --------------------------------------------------------------------------
 // Mode-9 warp fields (reference: src/caffe/WarpFields.cpp = WF).

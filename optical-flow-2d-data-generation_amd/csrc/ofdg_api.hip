@@ -116,16 +116,29 @@ struct ofdg_ctx {
   struct Chain {
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> cov;
-    DevBuf<uint32_t> layer;  // rigid modes: [object][frame][H][W] texel | coverage << 24 (raster_kernel's layer pass)
     Slot slot;
     Stage stage;
     hipEvent_t ev_prep = nullptr;  // coverage ready (hand-over to a caller's stream)
     hipEvent_t ev_done = nullptr;  // the chain's last tracked compose ...
     bool done_pending = false;
     hipStream_t done_stream = nullptr;  // ... and the stream it ran on (the chain's own, or a caller's)
+    // A batch whose preparation kernels have been enqueued on this chain and whose compose has not: what launch_prepare
+    // hands to launch_compose (and, for the counter sampler, which samples it holds: the look-ahead of ofdg_forward_counter)
+    struct Prepared {
+      bool valid = false;
+      Slot* slot = nullptr;
+      long long first_index = -1;  // counter sampler: global index of the batch's first sample (-1: host blueprints)
+      int n = 0;
+      unsigned long long* box_cur = nullptr;
+      const DevCropRef* croptab = nullptr;
+      hipEvent_t* ev = nullptr;    // profiled launch: its event set
+      hipStream_t stream = nullptr;  // where the preparation was enqueued
+    } prep;
   };
   static constexpr int kMaxChains = 8;
   Chain chains[kMaxChains];
+  int lookahead = 0;      // counter sampler: batches prepared ahead of the call that composes them (0: none)
+  long long last_first = -1;  // first index of the previous ofdg_forward_counter call (the stride of the caller's sequence)
   int n_chains = 3;       // one hardware queue each: HIP maps streams onto GPU_MAX_HW_QUEUES (4 by default) queues
   unsigned next_chain = 0;
   int last_chain = 0;     // the chain and the slot the last launch used (ofdg_render_resident, debug read-back)
@@ -163,7 +176,7 @@ struct ofdg_ctx {
   int profiling = 0;  // 0 off, 1 compose kernel only, 2 all three kernels
   std::vector<hipEvent_t> ev;
   int ev_sets = 0, ev_stride = 1;
-  long long ev_count = 0, launch_count = 0;
+  long long ev_count = 0, ev_alloc = 0, launch_count = 0;  // event sets: composed / handed out (a prepared batch holds one)
   std::vector<ofdg_task> fw_tasks;
   std::vector<ofdg_blueprint> fw_bps;
 };
@@ -178,6 +191,7 @@ struct ofdg_ctx {
   } while (0)
 
 static void drop_counter_croptab(ofdg_ctx* c);
+static int discard_all_prepared(ofdg_ctx* c);
 static int texture_of_image(ofdg_ctx* c, const uint32_t* image, int w, int h, int tw, int th, uint32_t* out);
 
 extern "C" {
@@ -278,6 +292,7 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   // on four queues share a queue with the caller's streams and are slower than three.
   if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) c->n_chains = std::atoi(q) >= 8 ? 4 : 3;
   if (const char* v = std::getenv("OFDG_CHAINS")) c->n_chains = std::min(std::max(std::atoi(v), 1), (int)ofdg_ctx::kMaxChains);
+  if (const char* v = std::getenv("OFDG_LOOKAHEAD")) c->lookahead = std::max(std::atoi(v), 0);
   for (int i = 0; i < c->n_chains; ++i) {
     ofdg_ctx::Chain& ch = c->chains[i];
     if ((e = hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -329,7 +344,6 @@ void ofdg_destroy(ofdg_ctx* c) {
     drop_slot(ch.slot);
     drop_stage(ch.stage);
     ch.cov.release();
-    ch.layer.release();
     if (ch.ev_prep) (void)hipEventDestroy(ch.ev_prep);
     if (ch.ev_done) (void)hipEventDestroy(ch.ev_done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
@@ -359,6 +373,7 @@ static int pool_check_dims(ofdg_ctx* c, int n, int w, int h) {
 
 int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
   if (!c) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   int rc = pool_check_dims(c, n, w, h);
   if (rc != OFDG_OK) return rc;
   HIP_OK(c, hipDeviceSynchronize());
@@ -377,6 +392,7 @@ int ofdg_pool_alloc(ofdg_ctx* c, int n, int w, int h) {
 // it is smaller; DG:96-106), in two uniform arrays.  background_prep needs the originals: not available here.
 int ofdg_pool_alloc_mixed(ofdg_ctx* c, int n) {
   if (!c) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   if (n < 1) { c->err = "texture pool needs at least one image"; return OFDG_ETEXTURES; }
   const int W = c->prm.width, H = c->prm.height;
   HIP_OK(c, hipDeviceSynchronize());
@@ -405,6 +421,7 @@ int ofdg_pool_alloc_mixed(ofdg_ctx* c, int n) {
 // image `index` of a mixed pool: planar B,G,R u8 of any size >= 2 x 2
 int ofdg_pool_upload_mixed(ofdg_ctx* c, int index, const uint8_t* bgr_planar, int w, int h) {
   if (!c || !bgr_planar) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   if (!c->pool_mixed || index < 0 || index >= c->pool_n || w < 2 || h < 2) {
     c->err = "pool_upload_mixed: no mixed pool (ofdg_pool_alloc_mixed), bad index or image smaller than 2 x 2";
     return OFDG_ETEXTURES;
@@ -449,6 +466,7 @@ int ofdg_pool_synthetic(ofdg_ctx* c, int n, int w, int h, uint32_t seed) {
 
 int ofdg_pool_upload(ofdg_ctx* c, int index, const uint8_t* bgr_planar, int w, int h) {
   if (!c || !bgr_planar) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   if (!c->pool || index < 0 || index >= c->pool_n || w != c->pool_w || h != c->pool_h) {
     c->err = "pool_upload: index / size does not match the allocated pool";
     return OFDG_ETEXTURES;
@@ -495,13 +513,18 @@ int ofdg_pool_device(ofdg_ctx* c, void** ptr, unsigned long long* bytes, int mar
   HIP_OK(c, hipDeviceSynchronize());
   *ptr = (void*)c->pool;
   *bytes = (unsigned long long)c->pool_n * c->pool_w * c->pool_h * sizeof(uint32_t);
-  if (mark_written) c->pool_final = false;
+  if (mark_written) {
+    c->pool_final = false;
+    int rcd = discard_all_prepared(c);  // (batches prepared ahead would render the old contents)
+    if (rcd != OFDG_OK) return rcd;
+  }
   return OFDG_OK;
 }
 
 int ofdg_pool_device_mixed(ofdg_ctx* c, void** fg, unsigned long long* fg_bytes, void** bg, unsigned long long* bg_bytes) {
   if (!c || !fg || !fg_bytes || !bg || !bg_bytes) return OFDG_EINVAL;
   if (!c->pool_mixed) { c->err = "pool_device_mixed: needs a mixed pool (ofdg_pool_alloc_mixed)"; return OFDG_ETEXTURES; }
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (the caller is about to write the textures)
   HIP_OK(c, hipDeviceSynchronize());
   const unsigned long long px = (unsigned long long)c->prm.width * c->prm.height;
   *fg = (void*)c->pool_fg; *fg_bytes = (unsigned long long)c->pool_n * px * sizeof(uint32_t);
@@ -536,6 +559,7 @@ int ofdg_setup_of(const ofdg_ctx* c, ofdg_setup* su, ofdg_tex_entry* table, int 
 
 int ofdg_setup_alloc_pool(ofdg_ctx* c, const ofdg_setup* su, const ofdg_tex_entry* table) {
   if (!c || !su) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   if (su->width != c->prm.width || su->height != c->prm.height) { c->err = "setup_alloc_pool: the context was not created from this setup"; return OFDG_EINVAL; }
   if (su->pool_kind == OFDG_POOL_SYNTHETIC) return ofdg_pool_synthetic(c, su->n_tex, su->pool_w, su->pool_h, su->pool_seed);
   if (su->pool_kind != OFDG_POOL_MIXED) return ofdg_pool_alloc(c, su->n_tex, su->pool_w, su->pool_h);
@@ -771,18 +795,13 @@ static void bgprep_caps(const ofdg_ctx* c, int* cap_cw, int* cap_ch) {
   *cap_cw = cw; *cap_ch = ch;
 }
 
-// per-chain workspaces of a batch of n_shapes outlines and n_objects objects: coverage slots (every mode) and texture
-// layers (rigid modes).  Growing them waits for the device: every chain may be reading its own.
-static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes, size_t n_objects) {
-  const size_t plane = (size_t)c->prm.width * c->prm.height;
-  const size_t need_cov = n_shapes * 2 * plane + 16;
-  const size_t need_layer = c->prm.mode == 9 ? 0 : n_objects * 2 * plane;
-  if (need_cov <= c->chains[0].cov.cap && need_layer <= c->chains[0].layer.cap) return OFDG_OK;
+// per-chain coverage workspaces of a batch of n_shapes outlines.  Growing them waits for the device: every chain may be
+// reading its own.
+static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes) {
+  const size_t need_cov = n_shapes * 2 * (size_t)c->prm.width * c->prm.height + 16;
+  if (need_cov <= c->chains[0].cov.cap) return OFDG_OK;
   HIP_OK(c, hipDeviceSynchronize());
-  for (int k = 0; k < c->n_chains; ++k) {
-    HIP_OK(c, c->chains[k].cov.reserve(need_cov));
-    HIP_OK(c, c->chains[k].layer.reserve(need_layer));
-  }
+  for (int k = 0; k < c->n_chains; ++k) HIP_OK(c, c->chains[k].cov.reserve(need_cov));
   return OFDG_OK;
 }
 
@@ -814,13 +833,21 @@ static ofdg_ctx::Chain& take_chain(ofdg_ctx* c) {
 // the stream chain `ch` works on for a call made with the caller's stream `st`
 static hipStream_t chain_stream(const ofdg_ctx* c, const ofdg_ctx::Chain& ch, hipStream_t st) { return c->overlap ? ch.stream : st; }
 
-// [counter sampler ->] geom -> raster -> compose of the batch resident in `sl`, in order on chain `ch`.
-// `st` is the caller's stream: if it is not the chain's own stream (ofdg_stream), compose runs on `st` instead,
-// behind what the caller enqueued there (the outputs may still be read) and behind the chain's raster kernel.
-static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow,
-                           hipStream_t st, long long cs_first_index = -1) {
+// A prepared batch that will never be composed (the caller's sequence jumped, the pool changed, the chain's private slot is
+// needed for something else): forget it.  compose is what resets the slot's raster work list, so do that here.
+static int discard_prepared(ofdg_ctx* c, ofdg_ctx::Chain& ch) {
+  if (!ch.prep.valid) return OFDG_OK;
+  ch.prep.valid = false;
+  if (ch.prep.slot && ch.prep.slot->d_item_count) HIP_OK(c, hipMemsetAsync(ch.prep.slot->d_item_count, 0, sizeof(int), ch.prep.stream));
+  return OFDG_OK;
+}
+static int discard_all_prepared(ofdg_ctx* c) {
+  for (int k = 0; k < c->n_chains; ++k) { int rc = discard_prepared(c, c->chains[k]); if (rc != OFDG_OK) return rc; }
+  return OFDG_OK;
+}
+
+static RenderDims render_dims(const ofdg_ctx* c, const ofdg_ctx::Slot& sl) {
   const int W = c->prm.width, H = c->prm.height;
-  const int n_sf = sl.res_shapes * 2;
   RenderDims dm;
   dm.W = W; dm.H = H; dm.pool_w = c->pool_w; dm.pool_h = c->pool_h;
   dm.use_aa = c->prm.use_antialiasing ? 1 : 0;
@@ -830,19 +857,27 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   dm.tiles_y = (H + kTileH - 1) / kTileH;
   dm.bg_pitch = c->prm.background_prep ? 2 * W : c->bg_src.pitch;
   dm.fg_pitch = c->fg_src.pitch;
-  const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
+  return dm;
+}
+
+// The preparation kernels of the batch resident in `sl`, in order on chain `ch`: [counter sampler ->] geom -> raster
+//   `st` is the stream of the call the batch is prepared for (only OFDG_OVERLAP=0 prepares on it).
+static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, hipStream_t st, long long cs_first_index = -1,
+                          bool hand_over = true) {
+  const int W = c->prm.width, H = c->prm.height;
+  const int n_sf = sl.res_shapes * 2;
+  const RenderDims dm = render_dims(c, sl);
+  { int rc = discard_prepared(c, ch); if (rc != OFDG_OK) return rc; }
   hipEvent_t* ev = nullptr;
   if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
-    ev = &c->ev[(size_t)(c->ev_count % c->ev_sets) * 6];
+    ev = &c->ev[(size_t)(c->ev_alloc++ % c->ev_sets) * 6];
   c->launch_count++;
-  c->last_slot = &sl;
   if (!c->overlap) {
     // everything runs on the caller's stream; a caller that switches streams loses the ordering
     if (c->have_last_user_st && c->last_user_st != st) HIP_OK(c, hipDeviceSynchronize());
     c->last_user_st = st; c->have_last_user_st = true;
   }
   hipStream_t S = chain_stream(c, ch, st);
-  const bool foreign = S != st;  // the caller's stream is not the chain's
   uint8_t* cov = ch.cov.p;
   // the slot's records: written on another stream, or still read by a compose of another chain
   // (a user slot rendered again; the chain's private slot only ever sees its own stream)
@@ -877,36 +912,55 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
   // chain's stream and its own completion - both taken from the kernels' own dispatch packets (stop
   // events).  A start event would be a marker packet in front of the kernel, which delays its dispatch
   // by ~10 us and is then counted as kernel time; only geom (first of the three) has one.
+  // geom: outlines, boxes, raster work list -> raster: coverage slots + block masks (persistent waves over the list)
   hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, S,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
                         sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
+  // (a compose on a caller's stream takes the prepared batch over with the event on raster's own packet)
+  hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
+                        ev ? ev[3] : (hand_over ? ch.ev_prep : nullptr), 0,
+                        sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words, box_cur);
+  HIP_OK(c, hipGetLastError());
+  if (ev && hand_over) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
+  ch.prep.valid = true; ch.prep.slot = &sl; ch.prep.first_index = cs_first_index; ch.prep.n = sl.res_samples;
+  ch.prep.box_cur = box_cur; ch.prep.croptab = croptab; ch.prep.ev = ev; ch.prep.stream = S;
+  return OFDG_OK;
+}
+
+// compose of the batch chain `ch` has prepared.  `st` is the caller's stream: if it is not the chain's own stream
+// (ofdg_stream), compose runs on `st` instead, behind what the caller enqueued there (the outputs may still be read) and
+// behind the chain's preparation kernels.
+static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float* d_img1, float* d_flow, hipStream_t st) {
+  if (!ch.prep.valid) { c->err = "internal: compose without a prepared batch"; return OFDG_EINVAL; }
+  ofdg_ctx::Slot& sl = *ch.prep.slot;
+  const int W = c->prm.width, H = c->prm.height;
+  const RenderDims dm = render_dims(c, sl);
+  const int compose_grid = dm.tiles_x * dm.tiles_y * dm.n_samples * 4;  // one 64 x 4 strip per single-wave workgroup
+  hipEvent_t* ev = ch.prep.ev;
+  unsigned long long* box_cur = ch.prep.box_cur;
+  const DevCropRef* croptab = ch.prep.croptab;
+  uint8_t* cov = ch.cov.p;
+  c->last_slot = &sl;
+  ch.prep.valid = false;
+  const hipStream_t S = ch.prep.stream;
+  const bool foreign = S != st;  // the caller's stream is not the chain's
   const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
   const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
-  {
-    // rigid modes: the raster waves also render the objects' texture layers (what compose blends); mode 9 re-samples
-    // masks and textures through warp fields inside compose_deform and takes coverage slots + the pool itself
-    const LayerArgs LA{sl.d_shapes.p, sl.d_objects.p, fgpool, c->prm.mode == 9 ? nullptr : ch.layer.p, dm.fg_pitch};
-    // (a caller's stream takes the coverage over with the event on raster's own packet)
-    hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
-                          ev ? ev[3] : (foreign ? ch.ev_prep : nullptr), 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov,
-                          box_next, n_mask_words, box_cur, LA);
-    HIP_OK(c, hipGetLastError());
-  }
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
-  // Where compose runs: on the chain's stream, right behind raster - or, if the caller passed another stream,
-  // on THAT stream (in order with the caller's own work, which may still read the outputs) once the coverage
-  // is ready.  It is tracked by the chain's event whenever somebody else may have to wait for it: the chain
+  // Where compose runs: on the chain's stream, right behind the preparation - or, if the caller passed another stream,
+  // on THAT stream (in order with the caller's own work, which may still read the outputs) once the batch is prepared.
+  // It is tracked by the chain's event whenever somebody else may have to wait for it: the chain
   // itself (workspace, private slot) after a compose on a caller's stream, other chains for a shared slot.
   hipStream_t CS = S;
   if (foreign) {
-    if (ev) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
     HIP_OK(c, hipStreamWaitEvent(st, ch.ev_prep, 0));
     CS = st;
   }
   const bool shared_slot = &sl != &ch.slot;
   hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
-  hipEvent_t k_start = nullptr, k_stop = ev ? ev[5] : done;
+  // (profiled launches: start and stop are the timestamps of the compose kernel's own dispatch packet)
+  hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
                           sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
@@ -917,11 +971,11 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
                           sl.d_item_count);
   else if ((W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_rigid_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
-                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, ch.layer.p, bgpool,
+                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
                           d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   else
     hipExtLaunchKernelGGL(compose_rigid_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
-                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, ch.layer.p, bgpool,
+                          sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
                           d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count);
   HIP_OK(c, hipGetLastError());
   if (ev) {
@@ -935,6 +989,15 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
     sl.compose_pending = false;  // private slot on its own chain: stream order is all it needs
   }
   return OFDG_OK;
+}
+
+// preparation + compose of the batch resident in `sl`, in order on chain `ch`
+static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, float* d_img0, float* d_img1, float* d_flow,
+                           hipStream_t st, long long cs_first_index = -1) {
+  // (the preparation's completion event is only needed when compose runs on another stream than the chain's)
+  int rc = launch_prepare(c, ch, sl, st, cs_first_index, chain_stream(c, ch, st) != st);
+  if (rc != OFDG_OK) return rc;
+  return launch_compose(c, ch, d_img0, d_img1, d_flow, st);
 }
 
 // CImg get_resize(.., 3), enlarging branch: source index and weight of every destination pixel (running double sums,
@@ -1032,7 +1095,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
   {
     const int W = c->prm.width, H = c->prm.height;
-    { int rcw = reserve_workspaces(c, n_shapes, n_obj); if (rcw != OFDG_OK) return rcw; }
+    { int rcw = reserve_workspaces(c, n_shapes); if (rcw != OFDG_OK) return rcw; }
     HIP_OK(c, sl.d_items.reserve(n_shapes * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
     { int rcm = reserve_blockmask(c, sl, n_tasks); if (rcm != OFDG_OK) return rcm; }
     if (!sl.d_item_count) {
@@ -1161,7 +1224,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   HIP_OK(c, sl.d_verts.reserve(shapes_cap * 2 * kMaxVerts));
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n));
-  { int rcw = reserve_workspaces(c, shapes_cap, n_obj); if (rcw != OFDG_OK) return rcw; }
+  { int rcw = reserve_workspaces(c, shapes_cap); if (rcw != OFDG_OK) return rcw; }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }
   if (c->prm.background_prep) {
@@ -1185,11 +1248,36 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
 int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
                          void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
-  // the chain samples and realises the batch on the device, then renders it: all in order on its stream
+  // A sample is a pure function of (seed, global index): the chain samples, realises and prepares the batch on the device
+  // and composes it, all in order on its stream.  Like the reference's prefetch thread (data_generation_layer.cpp:141-172)
+  // the context runs AHEAD of its caller: after composing batch k it enqueues the preparation of the batches the caller's
+  // sequence reaches next (first index + d x the stride of the last two calls, d = 1 .. lookahead) on the chains that
+  // will compose them, so a call normally finds its batch prepared and only launches compose.  A call for other samples
+  // than the prepared ones prepares its own (nothing is ever rendered from a stale preparation).
+  const int k = (int)(c->next_chain % (unsigned)c->n_chains);
   ofdg_ctx::Chain& ch = take_chain(c);
-  int rc = prepare_counter_slot(c, ch.slot, n_samples);
+  hipStream_t st = (hipStream_t)stream;
+  auto prepare_on = [&](ofdg_ctx::Chain& cj, long long first, hipStream_t s_, bool hand_over) -> int {
+    if (cj.prep.valid && cj.prep.slot == &cj.slot && cj.prep.first_index == first && cj.prep.n == n_samples) return OFDG_OK;
+    int rc = prepare_counter_slot(c, cj.slot, n_samples);
+    if (rc != OFDG_OK) return rc;
+    return launch_prepare(c, cj, cj.slot, s_, first, hand_over);
+  };
+  int rc = prepare_on(ch, first_index, st, chain_stream(c, ch, st) != st);
   if (rc != OFDG_OK) return rc;
-  return launch_resident(c, ch, ch.slot, d_img0, d_img1, d_flow, (hipStream_t)stream, first_index);
+  rc = launch_compose(c, ch, d_img0, d_img1, d_flow, st);
+  if (rc != OFDG_OK) return rc;
+  if (c->overlap && c->lookahead > 0) {
+    const long long stride = (c->last_first >= 0 && first_index > c->last_first) ? first_index - c->last_first
+                                                                                   : (long long)n_samples * std::max(1, c->prm.world_size);
+    for (int d = 1; d <= std::min(c->lookahead, c->n_chains - 1); ++d) {
+      ofdg_ctx::Chain& cj = c->chains[(k + d) % c->n_chains];
+      rc = prepare_on(cj, first_index + (long long)d * stride, cj.stream, true);  // (the stream of the call that composes it is not known yet)
+      if (rc != OFDG_OK) return rc;
+    }
+  }
+  c->last_first = first_index;
+  return OFDG_OK;
 }
 
 // The internal stream the NEXT render / forward call of this context works on (the chains take turns).
@@ -1349,6 +1437,7 @@ static int warp_alloc(ofdg_ctx* c, int n_crops) {
 // 17 times with themselves (x 2^17), cleaned, and cut into (W+1) x (H+1) crops.
 int ofdg_warp_generate(ofdg_ctx* c, int n_fields, uint32_t seed) {
   if (!c || n_fields < 1) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   const int W = c->prm.width, H = c->prm.height;
   const int S = std::max(W, H) * 3;
   std::vector<std::pair<int, int>> org;  // crop grid (WF:617-633)
@@ -1396,6 +1485,7 @@ int ofdg_warp_generate(ofdg_ctx* c, int n_fields, uint32_t seed) {
 // Install caller-provided crops: n x 4 planes (flow x, flow y, iflow x, iflow y) of (H+1)*(W+1) floats.
 int ofdg_warp_upload(ofdg_ctx* c, const float* crops, int n) {
   if (!c || !crops || n < 1) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }  // (batches prepared ahead read the old pool / crops)
   int rc = warp_alloc(c, n);
   if (rc != OFDG_OK) return rc;
   const size_t plane = (size_t)(c->prm.width + 1) * (c->prm.height + 1), crop_floats = 4 * plane;
@@ -1472,7 +1562,7 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   HIP_OK(c, hipMemcpy(sl.d_items.p, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(sl.d_item_count, &n_items, sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(raster_kernel, dim3(64 * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, 0, sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p,
-                     W, H, c->chains[0].cov.p, nullptr, 0, (unsigned long long*)nullptr, LayerArgs{nullptr, nullptr, nullptr, nullptr, 0});
+                     W, H, c->chains[0].cov.p, nullptr, 0, (unsigned long long*)nullptr);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipMemcpy(coverage_host, c->chains[0].cov.p, (size_t)W * H, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemset(sl.d_item_count, 0, sizeof(int)));
@@ -1518,8 +1608,10 @@ int ofdg_debug_item_count(ofdg_ctx* c) {
 int ofdg_set_profiling(ofdg_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return OFDG_EINVAL;
   HIP_OK(c, hipDeviceSynchronize());
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }
+  HIP_OK(c, hipDeviceSynchronize());
   c->profiling = mode;
-  c->ev_count = 0;
+  c->ev_count = 0; c->ev_alloc = 0;
   c->launch_count = 0;
   c->ev_stride = (mode == 1) ? 4 : 1;  // mode 1 samples every 4th launch: keeps the event cost out of throughput runs
   if (mode && c->ev.empty()) {
@@ -1550,8 +1642,8 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
     hipEvent_t* ev = &c->ev[(size_t)k * 6];
     HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
-    // geom: its own start marker .. its end; raster: end of geom .. its end; compose: end of raster .. its end
-    HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : 2 * i - 1], ev[2 * i + 1]));
+    // geom: its own start .. its end; raster: end of geom .. its end; compose: its own start .. its end
+    HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : (i == 2 ? 4 : 1)], ev[2 * i + 1]));
     acc += t;
   }
   *ms = (float)(acc / n);

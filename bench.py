@@ -23,7 +23,13 @@ ends with a device-wide synchronisation.
 
 Samples shard across ranks with no data-path collective ("weak" scaling): rank r renders block r of every
 B*world consecutive samples of the stream.  Start-up for N > 1: ONE native RCCL broadcast of rank 0's setup
-header + texture index table (ofdg_comm_bcast_setup, csrc/comm.cpp).
+header + texture index table (ofdg_comm_bcast_setup, csrc/comm.cpp); the JSON line carries the proof (`rccl_ranks` = what
+ncclCommCount says, `shards` = every rank's first global index of steps 0 and 1).  If the native start-up fails the run
+exits non-zero on every rank (--allow-fallback: the same header over torch.distributed instead, and the line says so).
+
+`reference_equivalent` in the same line: the same workload with background_prep = 1 - Texture::getRandomizedCrop(2W, 2H,
+rot, zoom, shift) on every sample's background, which the reference runs per sample (DataGenerator.cpp:1186-1192) and
+the headline skips - on the GPU and in the CPU-baseline leg.
 """
 import argparse
 import importlib
@@ -61,7 +67,7 @@ SEED = 20261003
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128):
+def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128, background_prep=0):
     """The oracle (CPU restatement of the reference path) timed on this host's cores, on a bounded sample of the
     same workload: 1 thread and all cores (the reference's threading: one sample worker per core,
     first_level_threads = cores, second_level_threads = 1, DataGenerator.cpp:1023-1027), in the reference's work
@@ -75,6 +81,7 @@ def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128):
     n_pool = min(host_pool, cfg["pool"][0])
     sub = np.stack([gen.pool_download(i) for i in range(n_pool)])  # tex_id % n_pool
     prm = oracle.default_params(W, H, mode, 1, 1, nobj)
+    prm.background_prep = background_prep
     crops = None
     if mode == 9:
         crops = np.stack([gen.warp_download(i) for i in range(min(gen.warp_count(), 8))])
@@ -107,7 +114,7 @@ def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128):
     return {"value": res["faithful_all"]["samples_per_s"], "unit": "samples/s", "cores": res["faithful_all"]["threads"], "kind": "port",
             "threads_all": res["faithful_all"]["samples_per_s"], "threads_1": res["faithful_1"]["samples_per_s"],
             "lean": {"threads_all": res["lean_all"]["samples_per_s"], "threads_1": res["lean_1"]["samples_per_s"]},
-            "host_logical_cpus": cores, "detail": res,
+            "host_logical_cpus": cores, "detail": res, "background_prep": background_prep,
             "sample": "oracle/ restatement on this workload (mode %d, %dx%d, %s objects), host pool = the first %d of the %d "
                       "textures; 'value' = the reference's work pattern (4 rasterisations + full-frame warps / blits per shape) on "
                       "%d worker threads; lean = one rasterisation per frame, work inside the outlines' boxes; %.0f s of CPU time in all"
@@ -123,6 +130,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pool", type=int, default=128, help="textures of the pool the CPU baseline works on")
     ap.add_argument("--sampler", choices=("counter", "resident"), default=None)
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the native RCCL start-up fails, broadcast the header over torch.distributed instead of exiting")
+    ap.add_argument("--no-reference-equivalent", action="store_true", help="skip the background_prep = 1 pass")
     ap.add_argument("--background-prep", action="store_true",
                     help="apply Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) to every background (DataGenerator.cpp:1186-1192)")
     args = ap.parse_args()
@@ -146,16 +156,25 @@ def main():
                               background_prep=1 if args.background_prep else 0)
     startup = "single process"
     gen = None
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")  # (barriers and the max over ranks of the timing below)
+        dist.init_process_group("nccl")  # (barriers, the gathers of the proof fields and the max over ranks of the timing)
+        # the one collective of this path, native: rank 0's seed / stream / pool header + texture index table in ONE
+        # ncclBroadcast on the library's own RCCL communicator (the unique id travels through the launcher's store).
+        # Success or failure is decided by all ranks together: a root that cannot set itself up broadcasts a failure
+        # status (bcast_abort) instead of leaving the others in the collective.
+        err = None
         try:
-            # the one collective of this path, native: rank 0's seed / stream / pool header + texture index table in ONE
-            # ncclBroadcast on the library's own RCCL communicator (the unique id travels through the launcher's store)
             comm = ofdg.Comm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
+            rccl_ranks = comm.nccl_count()
             if rank == 0:
-                gen = ofdg.Generator(prm)
-                gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+                try:
+                    gen = ofdg.Generator(prm)
+                    gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+                except Exception:
+                    comm.bcast_abort()
+                    raise
             setup, table = comm.bcast_setup(gen)
             if rank != 0:
                 prm = comm.params_of(setup)
@@ -163,7 +182,15 @@ def main():
                 gen.pool_from_setup(setup, table)
             comm.close()
             startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
-        except Exception as e:  # (a start-up problem must not cost the measurement: same header over torch.distributed)
+        except Exception as e:
+            err = e
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # (every rank gets here: nobody waits in a broadcast the root never entered)
+        if int(ok.item()) != 1:
+            if not args.allow_fallback:
+                sys.stderr.write("rank %d: native multi-GPU start-up failed%s\n" % (rank, ": %s" % err if err else " on another rank"))
+                dist.destroy_process_group()
+                raise SystemExit(3)
             header = torch.tensor([cfg["mode"], W, H, cfg["nobj"], *cfg["pool"], POOL_SEED, SEED], dtype=torch.int64, device="cuda")
             if rank != 0:
                 header.zero_()
@@ -174,7 +201,8 @@ def main():
                                       background_prep=1 if args.background_prep else 0)
             gen = ofdg.Generator(prm)
             gen.pool_synthetic(pn, pw, ph, pseed)
-            startup = "torch.distributed broadcast (native start-up failed: %s)" % str(e)[:200]
+            rccl_ranks = None
+            startup = "FALLBACK: torch.distributed broadcast (--allow-fallback; the native start-up failed: %s)" % str(err)[:200]
     else:
         gen = ofdg.Generator(prm)
         gen.pool_synthetic(*cfg["pool"], POOL_SEED)
@@ -230,6 +258,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # every rank's first global sample index of steps 0 and 1 (the sharding rule the library applies, gathered)
+    mine = torch.tensor([ofdg.shard_first_index(k, BATCH, world, rank) for k in (0, 1)], dtype=torch.int64, device="cuda")
+    shards = [mine.clone() for _ in range(world)]
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_gather(shards, mine)
+    shards = [[int(v) for v in t.tolist()] for t in shards]
+
+    # the reference-equivalent pass: the same workload with Texture::getRandomizedCrop on every background
+    ref_eq = None
+    if not args.no_reference_equivalent and not args.background_prep and counter:
+        prm2 = ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH, rank=rank,
+                                   world_size=world, device=local_rank, sampler=1, seed=SEED, background_prep=1)
+        gen2 = ofdg.Generator(prm2)
+        gen2.pool_synthetic(*cfg["pool"], POOL_SEED)
+        if cfg["mode"] == 9:
+            gen2.warp_generate(2, SEED)
+        steps2 = min(args.steps, 1000)
+        for i in range(args.warmup):
+            gen2.forward(*outs[i % NBUF], gen2.next_stream())
+        gen2.synchronize(stream)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps2):
+            gen2.forward(*outs[i % NBUF], gen2.next_stream())
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        barrier()
+        gen2.synchronize(stream)
+        t2 = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt2 = float(t2.item())
+        v2 = steps2 * BATCH * world / dt2
+        ref_eq = {"value": v2, "unit": "samples/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
+                  "whole_step_frac": v2 / world * 38 * W * H / 1e9 / HBM_PEAK_GBS, "background_prep": 1,
+                  "note": "background_prep = 1: getRandomizedCrop(2W, 2H, rot, zoom, shift) per sample (DataGenerator.cpp:1186-1192), "
+                          "the CImg chain stage by stage on the device; same algorithmic bytes as the headline (the prepared "
+                          "textures are extra traffic)"}
+        if world == 1 and not args.no_cpu_baseline:
+            ref_eq["cpu_baseline"] = cpu_baseline(ofdg, gen2, cfg, budget_s=12.0, host_pool=args.cpu_pool, background_prep=1)
+        del gen2
+
     compose_ms = gen.kernel_ms("compose")
     if rank == 0:
         # second short pass with all three kernels timed (not part of `value`)
@@ -266,7 +338,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
             "config": {"workload": cfg["name"], "baseline_config": args.config, "batch_per_gpu": BATCH,
-                       "background_prep": bool(args.background_prep), "startup": startup, "output_buffer_sets": NBUF,
+                       "background_prep": bool(args.background_prep), "startup": startup, "rccl_ranks": rccl_ranks,
+                       "shards": {"first_index_of_steps_0_and_1_by_rank": shards}, "context": gen.info(), "output_buffer_sets": NBUF,
                        "chains": gen.num_chains(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
                                    if counter else "ref (host mt19937 streams) inside the timed region" if cfg["sampler"] == "ref" else
@@ -291,6 +364,7 @@ def main():
             "kernel_ms": parts, "kernel_ms_alone": alone,
             "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
+        out["reference_equivalent"] = ref_eq
         if host_sampler_rate is not None:
             out["host_ref_sampler_samples_per_s"] = host_sampler_rate
         if world == 1 and not args.no_cpu_baseline:

@@ -116,7 +116,15 @@ typedef struct ofdg_params {
                                        int truncation, mirror) -> resize (per axis linear / moving average, u8 in between);
                                    2 = the same geometry as ONE resampling along the composed coordinate map (fast form:
                                        one interpolation less of blur, values differ from 1).  CImg itself: parity unpinned */
-  int32_t reserved[8];
+  /* how the context schedules its work (no effect on the bytes it renders; tests/test_gpu_sampler.py):
+   *   chains     internal in-order streams, each [sampler ->] geom -> raster -> compose of one batch (1..8).  0 = automatic:
+   *              4 when the process was started with GPU_MAX_HW_QUEUES >= 8 (one hardware queue per chain), else 3;
+   *              ofdg_ctx_info() says which and why
+   *   lookahead  counter sampler: batches whose preparation kernels are enqueued ahead of the call that composes them
+   *              (the reference's prefetch thread, LAY:141-172); 0 = none
+   *   serial     1 = everything on the caller's stream, one kernel after the other (debugging, per-kernel timing) */
+  int32_t chains, lookahead, serial;
+  int32_t reserved[5];
 } ofdg_params;
 
 typedef struct ofdg_ctx ofdg_ctx;
@@ -135,6 +143,10 @@ void ofdg_destroy(ofdg_ctx* ctx);
 const ofdg_params* ofdg_ctx_params(const ofdg_ctx* ctx);
 /* Message of the last failure on this ctx (or of a failed ofdg_create if ctx==NULL). */
 const char* ofdg_last_error(const ofdg_ctx* ctx);
+/* One line on how the context is set up: number of chains and what decided it (GPU_MAX_HW_QUEUES as the library found it
+ * when it was loaded; HIP reads the variable when the runtime starts, so it must be in the environment of the process),
+ * look-ahead, serial mode.  Valid until the ctx is destroyed. */
+const char* ofdg_ctx_info(const ofdg_ctx* ctx);
 
 /* ---- texture pool: replaces TextureCollection (DG:117-161) ---------------- */
 /* n seeded synthetic w x h textures generated directly in HBM. */
@@ -200,6 +212,12 @@ int ofdg_upload_slot(ofdg_ctx* ctx, int slot, const ofdg_task* tasks, int n_task
 int ofdg_render_slot(ofdg_ctx* ctx, int slot, float* d_image0, float* d_image1,
                      float* d_flow, void* stream);
 
+/* The sharding rule of ofdg_forward: step `step` of rank `rank` renders the global sample indices
+ * ofdg_shard_first_index(step, batch, world_size, rank) + [0, batch) = step * batch * world_size + rank * batch + [0, batch);
+ * over all ranks and steps these ranges tile the stream without gaps or overlap.  -1 for invalid arguments.
+ * (The reference has no counterpart: every solver's layer renders the same samples, data_generation_layer.hpp:54.) */
+long long ofdg_shard_first_index(long long step, int batch, int world_size, int rank);
+
 /* Replaces Forward_cpu/Forward_gpu (LAY:266-291): sample batch_size tasks and
  * render them. */
 int ofdg_forward(ofdg_ctx* ctx, float* d_image0, float* d_image1, float* d_flow,
@@ -261,6 +279,13 @@ int ofdg_host_displacers(int width, int height, uint32_t seed, double* out, int 
  * device rasteriser and return the raw AGG coverage (0..255) as w*h bytes. */
 int ofdg_debug_rasterize(ofdg_ctx* ctx, const double* xy, int n_vertices,
                          uint8_t* coverage_host);
+/* The same for a path with curve3 segments, flattened by the DEVICE (types[i]: 1 line_to, 3 curve3 control point
+ * followed by its end point; entry 0 is the move_to vertex; n <= 64): conv_curve / curve3_div as geom_kernel runs them
+ * (DG:493-517), pinned against compiled AGG in tests/test_gpu_parity.py. */
+int ofdg_debug_rasterize_path(ofdg_ctx* ctx, const double* xy, const int* types, int n, uint8_t* coverage_host);
+/* The DEVICE's span_interpolator_linear + dda2_line_interpolator (DG:203-216): out_xy[rows][len][2] = (x, y) in 24.8
+ * fixed point under the inverse affine inv[6] (AGG member order), before the filter's -128 offset. */
+int ofdg_debug_dda_rows(ofdg_ctx* ctx, const double* inv, int rows, int len, int* out_xy);
 /* After ofdg_render: raw coverage of rasterised shape `shape` of sample
  * `sample`, frame 0/1, as w*h host bytes (zero outside its bounding box). */
 int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
@@ -339,6 +364,8 @@ typedef struct ofdg_setup {
   int32_t pool_w, pool_h; /* image size (0 x 0 for a mixed pool) */
   uint32_t pool_seed;     /* synthetic pools */
   int32_t n_table;        /* valid entries of the index table that travels with the header */
+  int32_t status;         /* 0, or the root's error code (< 0): the root could not set itself up; every receiver fails with it */
+  int32_t max_shapes_per_sample;
   int32_t reserved;
 } ofdg_setup;
 /* One texture of the pool as the kernels address it: `offset` texels into the pool the foreground path reads,
@@ -359,10 +386,20 @@ void ofdg_comm_destroy(ofdg_comm* comm);
 int ofdg_comm_rank(const ofdg_comm* comm);
 int ofdg_comm_world_size(const ofdg_comm* comm);
 const char* ofdg_comm_last_error(const ofdg_comm* comm);
-/* THE start-up collective: root's *setup and table[0 .. setup->n_table) reach every rank in one ncclBroadcast. */
+/* THE start-up collective: root's *setup and table[0 .. setup->n_table) reach every rank in one ncclBroadcast.
+ * Success or failure is decided together: a root that cannot provide a setup (its context or texture collection failed,
+ * its table exceeds table_cap) still broadcasts - a header whose `status` carries its error code - so that every
+ * receiver returns that code instead of waiting for a broadcast that never comes (ofdg_comm_bcast_abort is that call
+ * for a root that failed before it had a setup at all). */
 int ofdg_comm_bcast_setup(ofdg_comm* comm, int root, ofdg_setup* setup, ofdg_tex_entry* table, int table_cap);
+int ofdg_comm_bcast_abort(ofdg_comm* comm, int root, int error_code, int table_cap);
+/* Ranks of the communicator as RCCL reports them (ncclCommCount): what a multi-GPU run prints as its proof that the
+ * native start-up really spanned world_size processes. */
+int ofdg_comm_nccl_count(ofdg_comm* comm);
 /* Replicate the root's resident pool into the (identically allocated) pools of the other ranks: ncclBroadcast
- * between the HBM pools, so that only the root reads the texture collection from disk (DG:117-149). */
+ * between the HBM pools, so that only the root reads the texture collection from disk (DG:117-149).  Every rank first
+ * checks that all of its buffers exist and the ranks agree on that (one ncclAllReduce of a flag) before the first
+ * payload broadcast: a rank that cannot take part makes the call fail on every rank. */
 int ofdg_comm_bcast_pool(ofdg_comm* comm, int root, ofdg_ctx* ctx);
 /* The header / index table of a context's stream and pool (what the root broadcasts), and the parameters a
  * receiving rank creates its context with (rank, world_size and device come from the communicator). */

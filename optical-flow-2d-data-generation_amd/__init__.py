@@ -54,7 +54,8 @@ class Params(C.Structure):
         ("first_level_threads", C.c_int32), ("second_level_threads", C.c_int32),
         ("num_objects", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("device", C.c_int32),
-        ("max_shapes_per_sample", C.c_int32), ("background_prep", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("max_shapes_per_sample", C.c_int32), ("background_prep", C.c_int32),
+        ("chains", C.c_int32), ("lookahead", C.c_int32), ("serial", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -62,7 +63,8 @@ class Setup(C.Structure):
     """ofdg_setup: what rank 0 broadcasts at start-up (stream + pool description)."""
     _fields_ = [(k, C.c_int32) for k in ("seed", "mode", "width", "height", "num_objects", "use_antialiasing", "batch_size",
                                          "sampler", "background_prep", "n_tex", "pool_kind", "pool_w", "pool_h")] + \
-               [("pool_seed", C.c_uint32), ("n_table", C.c_int32), ("reserved", C.c_int32)]
+               [("pool_seed", C.c_uint32), ("n_table", C.c_int32), ("status", C.c_int32), ("max_shapes_per_sample", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class TexEntry(C.Structure):
@@ -84,17 +86,17 @@ _lib = None
 
 # every symbol include/ofdg.h declares
 EXPORTS = [
-    "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error",
+    "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error", "ofdg_ctx_info",
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
-    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
-    "ofdg_debug_rasterize", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables", "ofdg_debug_detmath",
+    "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_shard_first_index", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
+    "ofdg_debug_rasterize", "ofdg_debug_rasterize_path", "ofdg_debug_dda_rows", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables", "ofdg_debug_detmath",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
     "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_num_chains",
     "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
-    "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_pool", "ofdg_setup_of", "ofdg_setup_params",
+    "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_abort", "ofdg_comm_nccl_count", "ofdg_comm_bcast_pool", "ofdg_setup_of", "ofdg_setup_params",
     "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_pool_device_image", "ofdg_layer_create_dist",
 ]
 
@@ -127,6 +129,8 @@ def lib():
         L.ofdg_destroy.restype = None
         L.ofdg_last_error.argtypes = [vp]
         L.ofdg_last_error.restype = C.c_char_p
+        L.ofdg_ctx_info.argtypes = [vp]
+        L.ofdg_ctx_info.restype = C.c_char_p
         L.ofdg_pool_synthetic.argtypes = [vp, i32, i32, i32, C.c_uint32]
         L.ofdg_pool_alloc.argtypes = [vp, i32, i32, i32]
         L.ofdg_pool_upload.argtypes = [vp, i32, vp, i32, i32]
@@ -146,6 +150,8 @@ def lib():
         L.ofdg_set_step.argtypes = [vp, C.c_longlong]
         L.ofdg_stream.restype = vp
         L.ofdg_debug_rasterize.argtypes = [vp, vp, i32, vp]
+        L.ofdg_debug_rasterize_path.argtypes = [vp, vp, vp, i32, vp]
+        L.ofdg_debug_dda_rows.argtypes = [vp, vp, i32, i32, vp]
         L.ofdg_debug_coverage.argtypes = [vp, i32, i32, i32, vp]
         L.ofdg_debug_num_shapes.argtypes = [vp, i32]
         L.ofdg_debug_tables.argtypes = [vp, vp, vp, vp, vp, i32]
@@ -185,6 +191,8 @@ def lib():
         L.ofdg_comm_last_error.restype = C.c_char_p
         L.ofdg_comm_bcast_setup.argtypes = [vp, i32, C.POINTER(Setup), vp, i32]
         L.ofdg_comm_bcast_pool.argtypes = [vp, i32, vp]
+        L.ofdg_comm_bcast_abort.argtypes = [vp, i32, i32, i32]
+        L.ofdg_comm_nccl_count.argtypes = [vp]
         L.ofdg_setup_of.argtypes = [vp, C.POINTER(Setup), vp, i32]
         L.ofdg_setup_params.argtypes = [C.POINTER(Setup), vp, C.POINTER(Params)]
         L.ofdg_setup_alloc_pool.argtypes = [vp, C.POINTER(Setup), vp]
@@ -193,6 +201,14 @@ def lib():
         L.ofdg_layer_create_dist.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
         _lib = L
     return _lib
+
+
+def shard_first_index(step, batch, world_size, rank):
+    """First global sample index of step `step` on rank `rank` (the rule ofdg_forward shards the stream by)."""
+    L = lib()
+    L.ofdg_shard_first_index.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
+    L.ofdg_shard_first_index.restype = C.c_longlong
+    return int(L.ofdg_shard_first_index(step, batch, world_size, rank))
 
 
 def default_params(**kw):
@@ -217,6 +233,10 @@ class Generator:
     def _check(self, rc):
         if rc != OK:
             raise OfdgError(rc, lib().ofdg_last_error(self.h).decode())
+
+    def info(self):
+        """How the context is set up (chains and what decided their number, look-ahead, serial mode)."""
+        return lib().ofdg_ctx_info(self.h).decode()
 
     def close(self):
         if getattr(self, "h", None):
@@ -414,6 +434,24 @@ class Generator:
         self._check(lib().ofdg_debug_rasterize(self.h, xy.ctypes.data_as(C.c_void_p), len(xy), cov.ctypes.data_as(C.c_void_p)))
         return cov
 
+    def debug_rasterize_path(self, xy, types):
+        """A path with curve3 segments through the device's flattening and rasteriser (ofdg_debug_rasterize_path)."""
+        import numpy as np
+        xy = np.ascontiguousarray(xy, np.float64)
+        types = np.ascontiguousarray(types, np.int32)
+        cov = np.zeros((self.params.height, self.params.width), np.uint8)
+        self._check(lib().ofdg_debug_rasterize_path(self.h, xy.ctypes.data_as(C.c_void_p), types.ctypes.data_as(C.c_void_p), len(xy),
+                                                    cov.ctypes.data_as(C.c_void_p)))
+        return cov
+
+    def debug_dda_rows(self, inv, rows, length):
+        """(x, y) in 24.8 fixed point of every pixel of `rows` output rows under the inverse affine (device interpolator)."""
+        import numpy as np
+        inv = np.ascontiguousarray(inv, np.float64)
+        out = np.zeros((rows, length, 2), np.int32)
+        self._check(lib().ofdg_debug_dda_rows(self.h, inv.ctypes.data_as(C.c_void_p), rows, length, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def debug_num_shapes(self, sample):
         n = lib().ofdg_debug_num_shapes(self.h, sample)
         if n < 0:
@@ -464,7 +502,7 @@ class Comm:
     rendezvous the launcher offers (`exchange`: a callable bytes-or-None -> bytes, e.g. a torch.distributed store);
     Comm(id, rank, world, device) binds the device and joins.  bcast_setup is THE start-up collective."""
 
-    TABLE_CAP = 16384
+    TABLE_CAP = 65536
 
     @staticmethod
     def unique_id():
@@ -496,15 +534,28 @@ class Comm:
             raise OfdgError(rc, lib().ofdg_comm_last_error(self.h).decode())
 
     def bcast_setup(self, gen=None, root=0):
-        """Root passes its Generator (stream + pool description are read off it); returns (Setup, table)."""
+        """Root passes its Generator (stream + pool description are read off it); returns (Setup, table).
+        A root that has no Generator to pass (its own set-up failed) calls bcast_abort instead: success or failure of
+        the start-up is decided by all ranks together, nobody is left waiting in the broadcast."""
         su = Setup()
         table = (TexEntry * self.TABLE_CAP)()
         if self.rank == root:
             rc = lib().ofdg_setup_of(gen.h, C.byref(su), table, self.TABLE_CAP)
             if rc != OK:
-                raise OfdgError(rc, "ofdg_setup_of")
+                su.status = rc
         self._check(lib().ofdg_comm_bcast_setup(self.h, root, C.byref(su), table, self.TABLE_CAP))
         return su, table
+
+    def bcast_abort(self, code=EINVAL, root=0):
+        """The root's side of a failed start-up: the receivers' bcast_setup raises with `code`."""
+        return lib().ofdg_comm_bcast_abort(self.h, root, int(code), self.TABLE_CAP)
+
+    def nccl_count(self):
+        """Number of ranks RCCL itself reports for the communicator (ncclCommCount)."""
+        n = lib().ofdg_comm_nccl_count(self.h)
+        if n < 0:
+            self._check(n)
+        return n
 
     def params_of(self, setup):
         p = Params()

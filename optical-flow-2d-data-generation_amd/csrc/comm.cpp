@@ -27,6 +27,8 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -47,8 +49,11 @@ Rccl* rccl(std::string* err) {
       r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
       r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
       r.Broadcast = (decltype(r.Broadcast))dlsym(r.so, "ncclBroadcast");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.so, "ncclAllReduce");
+      r.CommCount = (decltype(r.CommCount))dlsym(r.so, "ncclCommCount");
       r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString) r.err = "RCCL lacks a required symbol";
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllReduce || !r.CommCount || !r.GetErrorString)
+        r.err = "RCCL lacks a required symbol";
     }
   }
   if (!r.err.empty()) {
@@ -162,7 +167,15 @@ int ofdg_comm_bcast_setup(ofdg_comm* c, int root, ofdg_setup* setup, ofdg_tex_en
   }
   Rccl* R = rccl(&c->err);
   if (!R) return OFDG_EHIP;
-  if (c->rank == root && (setup->n_tex < 0 || setup->n_table > table_cap)) { c->err = "ofdg_comm_bcast_setup: root's table exceeds table_cap"; return OFDG_EINVAL; }
+  // a root that cannot provide its setup says so IN the broadcast (status): the receivers are already waiting for it
+  int root_failure = OFDG_OK;
+  if (c->rank == root) {
+    if (setup->status < 0) root_failure = setup->status;
+    else if (setup->n_tex < 0 || setup->n_table < 0 || setup->n_table > table_cap) {
+      root_failure = OFDG_ECAPACITY;
+      c->err = "ofdg_comm_bcast_setup: root's table exceeds table_cap";
+    }
+  }
   COMM_HIP(c, hipSetDevice(c->device));
   const size_t bytes = sizeof(ofdg_setup) + (size_t)table_cap * sizeof(ofdg_tex_entry);
   if (bytes > c->d_bytes) {
@@ -173,16 +186,63 @@ int ofdg_comm_bcast_setup(ofdg_comm* c, int root, ofdg_setup* setup, ofdg_tex_en
   }
   std::vector<char> host(bytes, 0);
   if (c->rank == root) {
-    std::memcpy(host.data(), setup, sizeof(ofdg_setup));
-    if (setup->n_table > 0) std::memcpy(host.data() + sizeof(ofdg_setup), table, (size_t)setup->n_table * sizeof(ofdg_tex_entry));
+    ofdg_setup hdr = *setup;
+    if (root_failure != OFDG_OK) { hdr.status = root_failure; hdr.n_table = 0; }
+    std::memcpy(host.data(), &hdr, sizeof(ofdg_setup));
+    if (hdr.n_table > 0) std::memcpy(host.data() + sizeof(ofdg_setup), table, (size_t)hdr.n_table * sizeof(ofdg_tex_entry));
     COMM_HIP(c, hipMemcpyAsync(c->d_buf, host.data(), bytes, hipMemcpyHostToDevice, c->stream));
   }
   COMM_NCCL(c, R, R->Broadcast(c->d_buf, c->d_buf, bytes, ncclUint8, root, c->comm, c->stream));
   COMM_HIP(c, hipMemcpyAsync(host.data(), c->d_buf, bytes, hipMemcpyDeviceToHost, c->stream));
   COMM_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->rank == root && root_failure != OFDG_OK) {
+    if (c->err.empty()) c->err = "ofdg_comm_bcast_setup: the root reported failure " + std::to_string(root_failure);
+    return root_failure;
+  }
   std::memcpy(setup, host.data(), sizeof(ofdg_setup));
+  if (setup->status < 0) {
+    c->err = "start-up failed on the root rank (error code " + std::to_string(setup->status) + "); see its message";
+    return setup->status;
+  }
   if (setup->n_table < 0 || setup->n_table > table_cap) { c->err = "ofdg_comm_bcast_setup: the root's table does not fit this rank's table_cap"; return OFDG_ECAPACITY; }
   if (setup->n_table > 0) std::memcpy(table, host.data() + sizeof(ofdg_setup), (size_t)setup->n_table * sizeof(ofdg_tex_entry));
+  return OFDG_OK;
+}
+
+int ofdg_comm_bcast_abort(ofdg_comm* c, int root, int error_code, int table_cap) {
+  if (!c) return OFDG_EINVAL;
+  ofdg_setup su;
+  std::memset(&su, 0, sizeof(su));
+  su.status = error_code < 0 ? error_code : OFDG_EINVAL;
+  std::vector<ofdg_tex_entry> table((size_t)(table_cap > 0 ? table_cap : 1));
+  (void)ofdg_comm_bcast_setup(c, root, &su, table.data(), table_cap);
+  return su.status;
+}
+
+int ofdg_comm_nccl_count(ofdg_comm* c) {
+  if (!c) return OFDG_EINVAL;
+  Rccl* R = rccl(&c->err);
+  if (!R) return OFDG_EHIP;
+  int n = 0;
+  COMM_NCCL(c, R, R->CommCount(c->comm, &n));
+  return n;
+}
+
+// do all ranks say `ok`?  (one ncclAllReduce(min) of a flag)
+static int comm_agree(ofdg_comm* c, Rccl* R, bool ok, bool* all_ok) {
+  const size_t need = sizeof(int);
+  if (c->d_bytes < need) {
+    if (c->d_buf) COMM_HIP(c, hipFree(c->d_buf));
+    c->d_buf = nullptr;
+    COMM_HIP(c, hipMalloc(&c->d_buf, 256));
+    c->d_bytes = 256;
+  }
+  int flag = ok ? 1 : 0;
+  COMM_HIP(c, hipMemcpyAsync(c->d_buf, &flag, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  COMM_NCCL(c, R, R->AllReduce(c->d_buf, c->d_buf, 1, ncclInt32, ncclMin, c->comm, c->stream));
+  COMM_HIP(c, hipMemcpyAsync(&flag, c->d_buf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  COMM_HIP(c, hipStreamSynchronize(c->stream));
+  *all_ok = flag == 1;
   return OFDG_OK;
 }
 
@@ -193,25 +253,35 @@ int ofdg_comm_bcast_pool(ofdg_comm* c, int root, ofdg_ctx* ctx) {
   if (!c || !ctx || root < 0 || root >= c->world) return OFDG_EINVAL;
   Rccl* R = rccl(&c->err);
   if (!R) return OFDG_EHIP;
+  // every buffer this rank takes part with, looked up BEFORE the first payload broadcast ...
   void *ptr = nullptr, *ptr2 = nullptr;
   unsigned long long bytes = 0, bytes2 = 0;
+  std::vector<std::pair<void*, unsigned long long>> images;
   int rc = ofdg_pool_device(ctx, &ptr, &bytes, c->rank != root);
   if (rc == OFDG_ETEXTURES) rc = ofdg_pool_device_mixed(ctx, &ptr, &bytes, &ptr2, &bytes2);  // images of different sizes
-  if (rc != OFDG_OK) { c->err = std::string("ofdg_pool_device: ") + ofdg_last_error(ctx); return rc; }
-  COMM_HIP(c, hipSetDevice(c->device));
-  COMM_NCCL(c, R, R->Broadcast(ptr, ptr, (size_t)bytes, ncclUint8, root, c->comm, c->stream));
-  if (ptr2) COMM_NCCL(c, R, R->Broadcast(ptr2, ptr2, (size_t)bytes2, ncclUint8, root, c->comm, c->stream));
-  if (ptr2 && ofdg_ctx_params(ctx)->background_prep) {  // mixed pool + background preparation: the whole images too
+  if (rc != OFDG_OK) c->err = std::string("ofdg_pool_device: ") + ofdg_last_error(ctx);
+  if (rc == OFDG_OK && ptr2 && ofdg_ctx_params(ctx)->background_prep) {  // mixed pool + background preparation: the whole images too
     int n = 0;
     ofdg_pool_info(ctx, &n, nullptr, nullptr);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && rc == OFDG_OK; ++i) {
       void* ip = nullptr;
       unsigned long long ib = 0;
       rc = ofdg_pool_device_image(ctx, i, &ip, &ib);
-      if (rc != OFDG_OK) { c->err = std::string("ofdg_pool_device_image: ") + ofdg_last_error(ctx); return rc; }
-      COMM_NCCL(c, R, R->Broadcast(ip, ip, (size_t)ib, ncclUint8, root, c->comm, c->stream));
+      if (rc != OFDG_OK) c->err = std::string("ofdg_pool_device_image: ") + ofdg_last_error(ctx);
+      else images.emplace_back(ip, ib);
     }
   }
+  COMM_HIP(c, hipSetDevice(c->device));
+  // ... and the ranks agree that everybody can: a rank that returned early would leave the others in ncclBroadcast
+  bool all_ok = false;
+  { int rca = comm_agree(c, R, rc == OFDG_OK, &all_ok); if (rca != OFDG_OK) return rca; }
+  if (!all_ok) {
+    if (rc == OFDG_OK) { c->err = "ofdg_comm_bcast_pool: another rank could not provide its pool buffers"; rc = OFDG_ETEXTURES; }
+    return rc;
+  }
+  COMM_NCCL(c, R, R->Broadcast(ptr, ptr, (size_t)bytes, ncclUint8, root, c->comm, c->stream));
+  if (ptr2) COMM_NCCL(c, R, R->Broadcast(ptr2, ptr2, (size_t)bytes2, ncclUint8, root, c->comm, c->stream));
+  for (const auto& im : images) COMM_NCCL(c, R, R->Broadcast(im.first, im.first, (size_t)im.second, ncclUint8, root, c->comm, c->stream));
   COMM_HIP(c, hipStreamSynchronize(c->stream));
   return OFDG_OK;
 }
@@ -221,7 +291,7 @@ int ofdg_setup_params(const ofdg_setup* su, const ofdg_comm* c, ofdg_params* p) 
   ofdg_default_params(p);
   p->seed = su->seed; p->mode = su->mode; p->width = su->width; p->height = su->height; p->num_objects = su->num_objects;
   p->use_antialiasing = su->use_antialiasing; p->batch_size = su->batch_size; p->sampler = su->sampler;
-  p->background_prep = su->background_prep;
+  p->background_prep = su->background_prep; p->max_shapes_per_sample = su->max_shapes_per_sample;
   if (c) { p->rank = c->rank; p->world_size = c->world; p->device = c->device; }
   return OFDG_OK;
 }

@@ -143,6 +143,60 @@ __device__ __forceinline__ int flatten_curve3(double x1, double y1, double x2, d
 // bit k = the (dilated) box of an outline of foreground object k touches the block.  compose
 // reads its block's pair with one scalar load and visits exactly these objects.
 
+// A path of up to 64 segments (lane = segment; type 1 = line_to, 3 = curve3 control point followed by its end point,
+// segment 0 = the move_to vertex) flattened the way conv_curve + curve3_div do it.  type_of(i) / point(i, x, y) give a
+// segment's type and its point in OUTPUT coordinates.  Returns the vertex count; the box is per lane (reduce it).
+template <class OutPtr, class TypeFn, class PointFn>
+__device__ __forceinline__ int path_verts(int n_seg, TypeFn type_of, PointFn point, OutPtr out, double (*stack)[kCurveMaxDepth][5],
+                                          int2 (*stage)[kCurveMaxPts], uint32_t* __restrict__ err, int lane, int& minx, int& miny,
+                                          int& maxx, int& maxy) {
+  int n_verts = 0;
+  // segment i: 0 = the move_to vertex, Line -> 1 vertex, Curve3 -> its flattening
+  // (all but the first point), the Dummy after a Curve3 (its end point) -> nothing
+  const int t = (lane >= n_seg) ? 0 : (lane == 0 ? 1 : type_of(lane));
+  const bool is_curve = (t == 3);
+  const unsigned long long cmask = __ballot(is_curve);
+  const int slot = __popcll(cmask & ((1ull << lane) - 1ull));
+  bool overflow = false;
+  int cnt = 0;
+  int2 v0 = make_int2(0, 0);
+  if (t == 1) {
+    double x, y;
+    point(lane, x, y);
+    v0 = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
+    cnt = 1;
+  } else if (is_curve) {
+    if (slot < kCurveSlots) {
+      // conv_curve: curve3(ctrl = seg[i], to = seg[i+1]) from the current point seg[i-1]
+      double x1, y1, x2, y2, x3, y3;
+      const int ie = (lane + 1 < n_seg) ? lane + 1 : lane;
+      point(lane - 1, x1, y1); point(lane, x2, y2); point(ie, x3, y3);
+      cnt = flatten_curve3(x1, y1, x2, y2, x3, y3, stack[slot], stage[slot], kCurveMaxPts, &overflow);
+    } else {
+      overflow = true;
+    }
+  }
+  const int incl = wave_scan_incl(cnt);
+  n_verts = __shfl(incl, 63, 64);
+  const int off = incl - cnt;
+  if (n_verts > kMaxVerts) {
+    if (lane == 0) atomicOr(err, kErrVertCapacity);
+    n_verts = 0;
+  } else if (t == 1) {
+    out[off] = v0;
+    minx = v0.x; maxx = v0.x; miny = v0.y; maxy = v0.y;
+  } else if (cnt > 0) {
+    for (int k = 0; k < cnt; ++k) {
+      const int2 v = stage[slot][k];
+      out[off + k] = v;
+      minx = min(minx, v.x); maxx = max(maxx, v.x);
+      miny = min(miny, v.y); maxy = max(maxy, v.y);
+    }
+  }
+  if (overflow) atomicOr(err, kErrCurveCapacity);
+  return n_verts;
+}
+
 // The flattened outline of one (shape, frame): vertices in 24.8 fixed point written to `out` (global memory or LDS),
 // their number and bounding box (wave-reduced).  One wave; lanes = ellipse steps or path segments.
 // Reference: agg::ellipse (100 steps), conv_curve / curve3_div, ras_conv_int::upscale = iround(v * 256).
@@ -166,52 +220,9 @@ __device__ __forceinline__ int outline_verts(const DevShape& S, const Mat& M, co
       miny = min(miny, v.y); maxy = max(maxy, v.y);
     }
   } else {
-    const int n_seg = S.n_seg;
-    // segment i: 0 = the move_to vertex, Line -> 1 vertex, Curve3 -> its flattening
-    // (all but the first point), the Dummy after a Curve3 (its end point) -> nothing
-    const int t = (lane >= n_seg) ? 0 : (lane == 0 ? 1 : S.seg_type[lane]);
-    const bool is_curve = (t == 3);
-    const unsigned long long cmask = __ballot(is_curve);
-    const int slot = __popcll(cmask & ((1ull << lane) - 1ull));
-    bool overflow = false;
-    int cnt = 0;
-    int2 v0 = make_int2(0, 0);
-    if (t == 1) {
-      double x = (double)S.seg_x[lane], y = (double)S.seg_y[lane];
-      xform(M, x, y);
-      v0 = make_int2(iround_d(x * 256.0), iround_d(y * 256.0));
-      cnt = 1;
-    } else if (is_curve) {
-      if (slot < kCurveSlots) {
-        // conv_curve: curve3(ctrl = seg[i], to = seg[i+1]) from the current point seg[i-1]
-        double x1 = (double)S.seg_x[lane - 1], y1 = (double)S.seg_y[lane - 1];
-        double x2 = (double)S.seg_x[lane], y2 = (double)S.seg_y[lane];
-        const int ie = (lane + 1 < n_seg) ? lane + 1 : lane;
-        double x3 = (double)S.seg_x[ie], y3 = (double)S.seg_y[ie];
-        xform(M, x1, y1); xform(M, x2, y2); xform(M, x3, y3);
-        cnt = flatten_curve3(x1, y1, x2, y2, x3, y3, stack[slot], stage[slot], kCurveMaxPts, &overflow);
-      } else {
-        overflow = true;
-      }
-    }
-    const int incl = wave_scan_incl(cnt);
-    n_verts = __shfl(incl, 63, 64);
-    const int off = incl - cnt;
-    if (n_verts > kMaxVerts) {
-      if (lane == 0) atomicOr(err, kErrVertCapacity);
-      n_verts = 0;
-    } else if (t == 1) {
-      out[off] = v0;
-      minx = v0.x; maxx = v0.x; miny = v0.y; maxy = v0.y;
-    } else if (cnt > 0) {
-      for (int k = 0; k < cnt; ++k) {
-        const int2 v = stage[slot][k];
-        out[off + k] = v;
-        minx = min(minx, v.x); maxx = max(maxx, v.x);
-        miny = min(miny, v.y); maxy = max(maxy, v.y);
-      }
-    }
-    if (overflow) atomicOr(err, kErrCurveCapacity);
+    n_verts = path_verts(S.n_seg, [&](int i) { return S.seg_type[i]; },
+                         [&](int i, double& x, double& y) { x = (double)S.seg_x[i]; y = (double)S.seg_y[i]; xform(M, x, y); },
+                         out, stack, stage, err, lane, minx, miny, maxx, maxy);
   }
   minx = wave_min(minx); miny = wave_min(miny); maxx = wave_max(maxx); maxy = wave_max(maxy);
   return n_verts;
@@ -2176,6 +2187,31 @@ __global__ __launch_bounds__(256) void pool_resize_axis_kernel(const uint32_t* _
 }
 
 // include/ofdg_detmath.h evaluated on the device (tests: device == host bit for bit)
+// Debug entries of the tests: the device's curve flattening and span interpolator on caller-given doubles.
+// (path: one wave, the same path_verts the outlines go through; writes the vertices + their number)
+__global__ __launch_bounds__(64) void debug_path_kernel(const double* __restrict__ xy, const int* __restrict__ types, int n_seg,
+                                                        int2* __restrict__ verts, int* __restrict__ n_out, uint32_t* __restrict__ err) {
+  __shared__ double s_stack[kCurveSlots][kCurveMaxDepth][5];
+  __shared__ int2 s_stage[kCurveSlots][kCurveMaxPts];
+  const int lane = (int)threadIdx.x;
+  int minx = 0x7FFFFFFF, miny = 0x7FFFFFFF, maxx = (int)0x80000000, maxy = (int)0x80000000;
+  const int n = path_verts(n_seg, [&](int i) { return types[i]; }, [&](int i, double& x, double& y) { x = xy[2 * i]; y = xy[2 * i + 1]; },
+                           verts, s_stack, s_stage, err, lane, minx, miny, maxx, maxy);
+  if (lane == 0) *n_out = n;
+}
+// (span interpolator: make_row + dda_at of `rows` output rows of length `len` under the inverse affine `inv`)
+__global__ void debug_dda_kernel(Mat inv, int rows, int len, int2* __restrict__ out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= rows * len) return;
+  const int y = i / len, x = i - y * len;
+  const int nshift = ((len & (len - 1)) == 0) ? (31 - __clz(len)) : -1;
+  const RowDDA R = make_row(inv, y, len, nshift);
+  out[i] = make_int2(dda_at(R.x1, R.lx, R.rx, len, nshift, x), dda_at(R.y1, R.ly, R.ry, len, nshift, x));
+}
+
+// ofdg_poll_errors: read and clear the device error word in one step
+__global__ void err_exchange_kernel(uint32_t* __restrict__ d_err, uint32_t* __restrict__ out) { *out = atomicExch(d_err, 0u); }
+
 __global__ void detmath_kernel(const double* __restrict__ a, int n, double* __restrict__ s, double* __restrict__ c,
                                const float* __restrict__ x, int m, float* __restrict__ e) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

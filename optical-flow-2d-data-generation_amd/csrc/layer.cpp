@@ -146,6 +146,8 @@ void parse_message(Lexer& lx, const std::string& scope, LayerConfig* cfg, bool t
       else if (f == "height") p.height = to_int(v, key);
       else if (f == "num_objects") p.num_objects = to_int(v, key);
       else if (f == "seed") p.seed = to_int(v, key);
+      else if (f == "chains") p.chains = to_int(v, key);        // scheduling (extension keys): internal streams,
+      else if (f == "lookahead") p.lookahead = to_int(v, key);  // batches prepared ahead of the Forward that composes them
       else if (f == "background_prep")  // true / 1: the CImg chain stage by stage; fast / 2: one resampling; false / 0: centre crop
         p.background_prep = (v.text == "true" || v.text == "1") ? 1 : (v.text == "fast" || v.text == "2") ? 2 : 0;
       else if (f == "sampler") p.sampler = (v.text == "counter") ? OFDG_SAMPLER_COUNTER : OFDG_SAMPLER_REF;
@@ -256,7 +258,7 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
 // ---------------------------------------------------------------------------
 DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg_comm* comm) : cfg_(parse_layer_prototxt(layer_prototxt)) {
   if (!cfg_.type.empty() && cfg_.type != "DataGeneration") throw std::runtime_error("layer type is not \"DataGeneration\"");
-  constexpr int kTableCap = 16384;
+  constexpr int kTableCap = 65536;
   std::vector<ofdg_tex_entry> table;
   ofdg_setup su;
   std::memset(&su, 0, sizeof(su));
@@ -278,11 +280,18 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg
       cfg_.params.rank = mine.rank; cfg_.params.world_size = mine.world_size; cfg_.params.device = mine.device;
     }
     if (!comm || rank == 0) {
-      create();
-      load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+      try {
+        create();
+        load_texture_collection(ctx_, cfg_.texture_dbases);  // DataGenerator ctor -> TextureCollection (DataGenerator.cpp:992)
+      } catch (...) {
+        // the other ranks are waiting in the start-up broadcast: tell them that it failed, then fail here
+        if (comm) (void)ofdg_comm_bcast_abort(comm, 0, OFDG_ETEXTURES, kTableCap);
+        throw;
+      }
       if (comm) {
         table.resize(kTableCap);
-        ofdg_setup_of(ctx_, &su, table.data(), kTableCap);
+        int rcs = ofdg_setup_of(ctx_, &su, table.data(), kTableCap);
+        if (rcs != OFDG_OK) su.status = rcs;  // (travels with the broadcast: every rank fails together)
         bcast();
       }
     } else {

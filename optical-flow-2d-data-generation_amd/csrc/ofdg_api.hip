@@ -25,6 +25,9 @@
 using namespace ofdg;
 
 static thread_local std::string g_create_error;
+// GPU_MAX_HW_QUEUES as the process environment had it when this library was loaded: HIP reads the variable once, when the
+// runtime starts, so what counts is the environment the process was started with
+static const int g_hw_queues_env = [] { const char* q = std::getenv("GPU_MAX_HW_QUEUES"); return q ? std::atoi(q) : 0; }();
 
 template <typename T>
 struct DevBuf {
@@ -44,6 +47,7 @@ struct DevBuf {
 struct ofdg_ctx {
   ofdg_params prm;
   std::string err;
+  std::string info;
   // texture pool
   uint32_t* pool = nullptr;
   int pool_n = 0, pool_w = 0, pool_h = 0;
@@ -143,7 +147,7 @@ struct ofdg_ctx {
   unsigned next_chain = 0;
   int last_chain = 0;     // the chain and the slot the last launch used (ofdg_render_resident, debug read-back)
   Slot* last_slot = nullptr;
-  hipStream_t last_user_st = nullptr;  // OFDG_OVERLAP=0: the caller's stream of the last launch
+  hipStream_t last_user_st = nullptr;  // serial mode: the caller's stream of the last launch
   bool have_last_user_st = false;
   // device counter sampler (OFDG_SAMPLER_COUNTER)
   CsMode cs_mode;
@@ -169,6 +173,7 @@ struct ofdg_ctx {
   DevBuf<uint16_t> d_bg_at_x, d_bg_at_y;
   DevBuf<double> d_bg_alpha_x, d_bg_alpha_y;
   int bg_tab_w = 0, bg_tab_h = 0;
+  int bg_cap_cw = 0, bg_cap_ch = 0, bg_cap_n = -1;  // bgprep_caps of the current pool (reset when the pool changes)
   uint32_t* h_err = nullptr;        // pinned copy for ofdg_poll_errors, on its own stream
   hipStream_t err_stream = nullptr;
   // profiling: ring of event sets, 6 events per launch: start/stop of geom, raster and compose,
@@ -286,13 +291,18 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
   }
-  if (const char* v = std::getenv("OFDG_OVERLAP")) c->overlap = std::atoi(v) != 0;  // 0: everything on the caller's stream
+  c->overlap = params->serial == 0;  // serial: everything on the caller's stream
+  c->lookahead = std::max(params->lookahead, 0);
   // One hardware queue per chain: HIP maps its streams onto GPU_MAX_HW_QUEUES (default 4) queues.  A process started
   // with GPU_MAX_HW_QUEUES >= 8 gets four chains (+5-8 % throughput, profiles/r02_chains_vs_hw_queues.txt); four chains
   // on four queues share a queue with the caller's streams and are slower than three.
-  if (const char* q = std::getenv("GPU_MAX_HW_QUEUES")) c->n_chains = std::atoi(q) >= 8 ? 4 : 3;
-  if (const char* v = std::getenv("OFDG_CHAINS")) c->n_chains = std::min(std::max(std::atoi(v), 1), (int)ofdg_ctx::kMaxChains);
-  if (const char* v = std::getenv("OFDG_LOOKAHEAD")) c->lookahead = std::max(std::atoi(v), 0);
+  c->n_chains = params->chains > 0 ? std::min(params->chains, (int)ofdg_ctx::kMaxChains) : (g_hw_queues_env >= 8 ? 4 : 3);
+  c->info = "chains=" + std::to_string(c->n_chains) +
+            (params->chains > 0 ? " (ofdg_params.chains)"
+             : g_hw_queues_env >= 8 ? " (GPU_MAX_HW_QUEUES=" + std::to_string(g_hw_queues_env) + ": one hardware queue per chain)"
+             : g_hw_queues_env > 0 ? " (GPU_MAX_HW_QUEUES=" + std::to_string(g_hw_queues_env) + " < 8: start the process with GPU_MAX_HW_QUEUES=8 for four chains, +5-8 %)"
+                                   : " (GPU_MAX_HW_QUEUES was not set when the library was loaded: HIP's default of 4 hardware queues; start the process with GPU_MAX_HW_QUEUES=8 for four chains, +5-8 %)") +
+            " lookahead=" + std::to_string(c->lookahead) + (c->overlap ? "" : " serial");
   for (int i = 0; i < c->n_chains; ++i) {
     ofdg_ctx::Chain& ch = c->chains[i];
     if ((e = hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -317,6 +327,7 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
 }
 
 const ofdg_params* ofdg_ctx_params(const ofdg_ctx* c) { return c ? &c->prm : nullptr; }
+const char* ofdg_ctx_info(const ofdg_ctx* c) { return c ? c->info.c_str() : ""; }
 
 void ofdg_destroy(ofdg_ctx* c) {
   if (!c) return;
@@ -539,7 +550,10 @@ int ofdg_setup_of(const ofdg_ctx* c, ofdg_setup* su, ofdg_tex_entry* table, int 
   const ofdg_params& p = c->prm;
   su->seed = p.seed; su->mode = p.mode; su->width = p.width; su->height = p.height; su->num_objects = p.num_objects;
   su->use_antialiasing = p.use_antialiasing; su->batch_size = p.batch_size; su->sampler = p.sampler;
-  su->background_prep = p.background_prep;
+  su->background_prep = p.background_prep; su->max_shapes_per_sample = p.max_shapes_per_sample;
+  // (a pool of images of different sizes needs every entry of the table: a table that does not fit is the root's failure,
+  //  which the broadcast carries to every rank)
+  if (c->pool_mixed && c->pool_n > table_cap) su->status = OFDG_ECAPACITY;
   su->n_tex = c->pool_n; su->pool_kind = c->pool_kind; su->pool_w = c->pool_w; su->pool_h = c->pool_h; su->pool_seed = c->pool_seed;
   su->n_table = std::min(c->pool_n, table_cap);
   const uint64_t W = (uint64_t)p.width, H = (uint64_t)p.height;
@@ -784,7 +798,8 @@ static int ensure_tex_table(ofdg_ctx* c) {
   HIP_OK(c, hipMemcpy(c->d_tex_table, c->tex_table.data(), c->tex_table.size() * sizeof(DevTexEntry), hipMemcpyHostToDevice));
   return OFDG_OK;
 }
-static void bgprep_caps(const ofdg_ctx* c, int* cap_cw, int* cap_ch) {
+static void bgprep_caps(ofdg_ctx* c, int* cap_cw, int* cap_ch) {
+  if (c->bg_cap_n == c->pool_n && c->bg_cap_cw > 0) { *cap_cw = c->bg_cap_cw; *cap_ch = c->bg_cap_ch; return; }  // (per pool, not per step)
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
   // crops of the rotated image up to zoom 0.75 (the sampler draws 0.8 .. 1.2) ...
   int cw = (int)((float)TW / 0.75f) + 2, ch = (int)((float)TH / 0.75f) + 2;
@@ -792,6 +807,7 @@ static void bgprep_caps(const ofdg_ctx* c, int* cap_cw, int* cap_ch) {
   auto small = [&](int w, int h) { if (w < TW || h < TH) { cw = std::max(cw, w + h / 8 + 4); ch = std::max(ch, h + w / 8 + 4); } };
   if (c->pool_mixed) for (const auto& wh : c->mixed_sizes) small(wh.first, wh.second);
   else small(c->pool_w, c->pool_h);
+  c->bg_cap_cw = cw; c->bg_cap_ch = ch; c->bg_cap_n = c->pool_n;
   *cap_cw = cw; *cap_ch = ch;
 }
 
@@ -842,6 +858,7 @@ static int discard_prepared(ofdg_ctx* c, ofdg_ctx::Chain& ch) {
   return OFDG_OK;
 }
 static int discard_all_prepared(ofdg_ctx* c) {
+  c->bg_cap_n = -1;  // (called by everything that changes the pool)
   for (int k = 0; k < c->n_chains; ++k) { int rc = discard_prepared(c, c->chains[k]); if (rc != OFDG_OK) return rc; }
   return OFDG_OK;
 }
@@ -861,7 +878,7 @@ static RenderDims render_dims(const ofdg_ctx* c, const ofdg_ctx::Slot& sl) {
 }
 
 // The preparation kernels of the batch resident in `sl`, in order on chain `ch`: [counter sampler ->] geom -> raster
-//   `st` is the stream of the call the batch is prepared for (only OFDG_OVERLAP=0 prepares on it).
+//   `st` is the stream of the call the batch is prepared for (only the serial mode prepares on it).
 static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, hipStream_t st, long long cs_first_index = -1,
                           bool hand_over = true) {
   const int W = c->prm.width, H = c->prm.height;
@@ -1314,13 +1331,20 @@ int ofdg_sample_counter(ofdg_ctx* c, long long first_index, int n_samples, ofdg_
   return OFDG_OK;
 }
 
+// The sharding rule: of the global sample stream, step `step` of rank `rank` renders the `batch` samples
+// starting at this index.  The ranks' ranges tile the stream: every index belongs to exactly one (step, rank).
+long long ofdg_shard_first_index(long long step, int batch, int world_size, int rank) {
+  if (step < 0 || batch < 1 || world_size < 1 || rank < 0 || rank >= world_size) return -1;
+  return step * (long long)batch * world_size + (long long)rank * batch;
+}
+
 int ofdg_forward(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
   if (!c) return OFDG_EINVAL;
   if (c->prm.sampler == OFDG_SAMPLER_COUNTER) {
     // rank r owns global indices step*B*world + r*B + [0, B)
     const int B = c->prm.batch_size, world = c->prm.world_size, rank = c->prm.rank;
     if (B < 1 || rank < 0 || rank >= world) { c->err = "ofdg_forward: bad batch_size / rank"; return OFDG_EINVAL; }
-    const long long first = c->step * (long long)B * world + (long long)rank * B;
+    const long long first = ofdg_shard_first_index(c->step, B, world, rank);
     const int rc = ofdg_forward_counter(c, first, B, d_img0, d_img1, d_flow, stream);
     if (rc == OFDG_OK) c->step++;  // (a failed call does not advance the checkpoint counter)
     return rc;
@@ -1399,14 +1423,17 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
 // a finished batch over; flags of younger batches are reported at their own hand-over at the latest).
 int ofdg_poll_errors(ofdg_ctx* c) {
   if (!c) return OFDG_EINVAL;
-  if (!c->h_err) HIP_OK(c, hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocDefault));
+  if (!c->h_err) HIP_OK(c, hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocMapped));
   if (!c->err_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->err_stream, hipStreamNonBlocking));
-  HIP_OK(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->err_stream));
+  // read AND clear in one atomic exchange (younger batches are still running and may raise a flag at any time: a copy
+  // followed by a memset would lose what is raised in between)
+  uint32_t* h_dev = nullptr;
+  HIP_OK(c, hipHostGetDevicePointer((void**)&h_dev, c->h_err, 0));
+  hipLaunchKernelGGL(err_exchange_kernel, dim3(1), dim3(1), 0, c->err_stream, c->d_err, h_dev);
+  HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->err_stream));
   const uint32_t e = *c->h_err;
   if (e) {
-    HIP_OK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->err_stream));
-    HIP_OK(c, hipStreamSynchronize(c->err_stream));
     c->err = "device capacity exceeded:";
     if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
     if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
@@ -1528,13 +1555,11 @@ int ofdg_host_displacers(int width, int height, uint32_t seed, double* out, int 
 // ---- inspection ---------------------------------------------------------------------------------
 static inline int iround_h(double v) { return int((v < 0.0) ? v - 0.5 : v + 0.5); }
 
-int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage_host) {
-  if (!c || !xy || !coverage_host || n < 1 || n > kMaxVerts) return OFDG_EINVAL;
+// rasterise ONE outline given as 24.8 vertices over the whole frame (slot 0 serves as scratch)
+static int debug_rasterize_verts(ofdg_ctx* c, const std::vector<int2>& v, int n, uint8_t* coverage_host) {
   const int W = c->prm.width, H = c->prm.height;
-  std::vector<int2> v(kMaxVerts);
   int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -0x7fffffff - 1, maxy = -0x7fffffff - 1;
   for (int i = 0; i < n; ++i) {
-    v[i] = make_int2(iround_h(xy[2 * i] * 256.0), iround_h(xy[2 * i + 1] * 256.0));
     minx = std::min(minx, v[i].x); maxx = std::max(maxx, v[i].x);
     miny = std::min(miny, v[i].y); maxy = std::max(maxy, v[i].y);
   }
@@ -1570,6 +1595,54 @@ int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage
   c->last_slot = nullptr;
   return OFDG_OK;
 }
+
+int ofdg_debug_rasterize(ofdg_ctx* c, const double* xy, int n, uint8_t* coverage_host) {
+  if (!c || !xy || !coverage_host || n < 1 || n > kMaxVerts) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }
+  std::vector<int2> v(kMaxVerts);
+  for (int i = 0; i < n; ++i) v[i] = make_int2(iround_h(xy[2 * i] * 256.0), iround_h(xy[2 * i + 1] * 256.0));
+  return debug_rasterize_verts(c, v, n, coverage_host);
+}
+
+// A path with curve3 segments (types: 1 line_to, 3 curve3 control point followed by its end point; entry 0 is the
+// move_to vertex) through the DEVICE's flattening (path_verts / flatten_curve3, what geom_kernel runs) and rasteriser.
+int ofdg_debug_rasterize_path(ofdg_ctx* c, const double* xy, const int* types, int n, uint8_t* coverage_host) {
+  if (!c || !xy || !types || !coverage_host || n < 1 || n > 64) return OFDG_EINVAL;
+  { int rcd = discard_all_prepared(c); if (rcd != OFDG_OK) return rcd; }
+  HIP_OK(c, hipDeviceSynchronize());
+  double* d_xy = nullptr; int* d_ty = nullptr; int2* d_v = nullptr; int* d_n = nullptr;
+  HIP_OK(c, hipMalloc((void**)&d_xy, sizeof(double) * 2 * n));
+  HIP_OK(c, hipMalloc((void**)&d_ty, sizeof(int) * n));
+  HIP_OK(c, hipMalloc((void**)&d_v, sizeof(int2) * kMaxVerts));
+  HIP_OK(c, hipMalloc((void**)&d_n, sizeof(int)));
+  HIP_OK(c, hipMemcpy(d_xy, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(d_ty, types, sizeof(int) * n, hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemset(d_v, 0, sizeof(int2) * kMaxVerts));
+  hipLaunchKernelGGL(debug_path_kernel, dim3(1), dim3(64), 0, 0, d_xy, d_ty, n, d_v, d_n, c->d_err);
+  HIP_OK(c, hipGetLastError());
+  std::vector<int2> v(kMaxVerts);
+  int nv = 0;
+  HIP_OK(c, hipMemcpy(v.data(), d_v, sizeof(int2) * kMaxVerts, hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemcpy(&nv, d_n, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d_xy); (void)hipFree(d_ty); (void)hipFree(d_v); (void)hipFree(d_n);
+  if (nv < 1 || nv > kMaxVerts) { c->err = "debug_rasterize_path: the flattened outline has " + std::to_string(nv) + " vertices"; return OFDG_ECAPACITY; }
+  return debug_rasterize_verts(c, v, nv, coverage_host);
+}
+
+// The DEVICE's span interpolator (make_row + dda_at, what the texture warps run): (x, y) in 24.8 fixed point of every
+// pixel of `rows` output rows of length `len` under the inverse affine inv[6] (AGG member order), before the -128.
+int ofdg_debug_dda_rows(ofdg_ctx* c, const double* inv, int rows, int len, int* out_xy) {
+  if (!c || !inv || !out_xy || rows < 1 || len < 1 || (size_t)rows * len > (1u << 24)) return OFDG_EINVAL;
+  int2* d = nullptr;
+  HIP_OK(c, hipMalloc((void**)&d, sizeof(int2) * (size_t)rows * len));
+  const Mat m{inv[0], inv[1], inv[2], inv[3], inv[4], inv[5]};
+  hipLaunchKernelGGL(debug_dda_kernel, dim3((rows * len + 255) / 256), dim3(256), 0, 0, m, rows, len, d);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipMemcpy(out_xy, d, sizeof(int2) * (size_t)rows * len, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return OFDG_OK;
+}
+
 int ofdg_debug_num_shapes(ofdg_ctx* c, int sample) {
   if (!c || !c->last_slot) return OFDG_EINVAL;
   const ofdg_ctx::Slot& sl = *c->last_slot;

@@ -146,7 +146,13 @@ BgPrep make_bg_prep(int pw, int ph, int W, int H, float angle, float zoom, int s
   const int TW = 2 * W, TH = 2 * H;
   const float nangle = cimg_modf(angle, 360.0f);
   const float rad = (float)(nangle * 3.14159265358979323846 / 180.0);
-  p.ca = std::cos(rad); p.sa = std::sin(rad);  // (float overloads, as in CImg)
+  if (detmath_flag()) {  // the device counter-sampler path: include/ofdg_detmath.h's fp64 sin / cos, rounded to float
+    double sa, ca;
+    ofdg_det_sincos((double)rad, &sa, &ca);
+    p.ca = (float)ca; p.sa = (float)sa;
+  } else {
+    p.ca = std::cos(rad); p.sa = std::sin(rad);  // (float overloads, as in CImg)
+  }
   const float ux = std::fabs((pw - 1) * p.ca), uy = std::fabs((pw - 1) * p.sa);
   const float vx = std::fabs((ph - 1) * p.sa), vy = std::fabs((ph - 1) * p.ca);
   const int rw = (int)std::floor(1 + ux + vx + 0.5f), rh = (int)std::floor(1 + uy + vy + 0.5f);

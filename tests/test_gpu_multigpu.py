@@ -93,19 +93,34 @@ def test_comm_joins_through_a_key_value_store(ofdg):
     c.close()
 
 
-def test_chain_count_follows_the_hardware_queue_setting(ofdg, monkeypatch):
-    """A process started with GPU_MAX_HW_QUEUES >= 8 gets four chains (one hardware queue each), otherwise three;
-    OFDG_CHAINS overrides (the library only reads the variable - HIP itself reads it when the runtime starts)."""
-    def chains(**env):
-        for k in ("GPU_MAX_HW_QUEUES", "OFDG_CHAINS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        g = ofdg.Generator(ofdg.default_params(width=64, height=48, mode=5))
-        n = g.num_chains()
-        g.close()
-        return n
-    assert chains() == 3
-    assert chains(GPU_MAX_HW_QUEUES="8") == 4
-    assert chains(GPU_MAX_HW_QUEUES="4") == 3
-    assert chains(GPU_MAX_HW_QUEUES="8", OFDG_CHAINS="2") == 2
+def test_chain_count_follows_the_hardware_queue_setting(ofdg, tmp_path):
+    """A process STARTED with GPU_MAX_HW_QUEUES >= 8 gets four chains (one hardware queue each), otherwise three, and
+    ofdg_ctx_info says which and why; ofdg_params.chains overrides.  The library takes the variable as it was when the
+    library was loaded (HIP itself reads it when the runtime starts): changing it afterwards changes nothing."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "chains.py"
+    script.write_text('''
+import importlib, os, sys
+sys.path.insert(0, %r)
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+ofdg.lib()
+os.environ["GPU_MAX_HW_QUEUES"] = "8"   # too late: not what the process was started with
+g = ofdg.Generator(ofdg.default_params(width=64, height=48, mode=5, **eval(sys.argv[1])))
+print(g.num_chains(), "|", g.info())
+''' % root)
+
+    def chains(kw, **env):
+        e = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        e.update(env)
+        out = subprocess.run([sys.executable, str(script), repr(kw)], check=True, env=e, timeout=300, capture_output=True, text=True).stdout
+        n, info = out.strip().splitlines()[-1].split(" | ")
+        return int(n), info
+    n, info = chains({})
+    assert n == 3 and "GPU_MAX_HW_QUEUES was not set" in info
+    n, info = chains({}, GPU_MAX_HW_QUEUES="8")
+    assert n == 4 and "one hardware queue per chain" in info
+    n, info = chains({}, GPU_MAX_HW_QUEUES="4")
+    assert n == 3 and "< 8" in info
+    n, info = chains({"chains": 2, "lookahead": 1}, GPU_MAX_HW_QUEUES="8")
+    assert n == 2 and "ofdg_params.chains" in info and "lookahead=1" in info

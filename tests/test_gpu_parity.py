@@ -99,6 +99,40 @@ def test_rasteriser_matches_agg_goldens(ofdg, agg):
         assert np.array_equal(cov, agg["poly_cov"][i]), "polygon %d: %d px differ" % (i, (cov != agg["poly_cov"][i]).sum())
 
 
+def test_curve_polygons_match_agg_on_the_device(ofdg, agg):
+    """Paths with curve3 segments through the DEVICE's flattening (path_verts / flatten_curve3: conv_curve + curve3_div,
+    what geom_kernel runs on every polygon outline) and rasteriser, against matplotlib's compiled AGG."""
+    W, H = [int(v) for v in agg["canvas"]]
+    g = make_gen(ofdg, W, H, 5)
+    off = 0
+    for i, n in enumerate(agg["cpoly_len"]):
+        xy = agg["cpoly_xy"][off:off + n]
+        types = agg["cpoly_types"][off:off + n]
+        off += n
+        cov = g.debug_rasterize_path(xy, types)
+        assert np.array_equal(cov, agg["cpoly_cov"][i]), "curve polygon %d: %d px differ" % (i, (cov != agg["cpoly_cov"][i]).sum())
+    g.synchronize()  # no capacity flag was raised
+
+
+def test_span_interpolator_matches_agg_on_the_device(ofdg, agg):
+    """The DEVICE's span interpolator (make_row + closed-form dda_at, what every texture warp runs) against the source
+    positions matplotlib's compiled AGG sampled (NEAREST resampling of an index image)."""
+    def agg_invert(m):
+        sx, shx, tx = m[0]
+        shy, sy, ty = m[1]
+        d = 1.0 / (sx * sy - shy * shx)
+        t0, sy2, shy2, shx2 = sy * d, sx * d, -shy * d, -shx * d
+        return [t0, shy2, shx2, sy2, -tx * t0 - ty * shx2, -tx * shy2 - ty * sy2]
+    g = make_gen(ofdg, 64, 48, 5)
+    SW, SH = [int(v) for v in agg["dda_src"]]
+    for i, m in enumerate(agg["dda_mats"]):
+        pos = agg["dda_pos"][i]
+        oh, ow = pos.shape
+        r = g.debug_dda_rows(agg_invert(m), oh, ow)
+        idx = (r[:, :, 1] >> 8) * SW + (r[:, :, 0] >> 8)
+        assert np.array_equal(idx, pos), "affine %d" % i
+
+
 def test_rasteriser_offscreen_and_clipped(ofdg, oracle):
     """Shapes crossing every screen edge, fully outside, larger than the screen, degenerate."""
     W, H = 128, 96
@@ -161,8 +195,8 @@ def test_rasteriser_long_edges_take_the_wide_arithmetic(ofdg, oracle):
 @pytest.mark.parametrize("mode", [1, 2, 3, 5, 7, 13])
 def test_render_matches_oracle_small(ofdg, oracle, mode, size):
     """End to end on a small frame: objects are large relative to the frame, so overlaps,
-    clipping, reflection at the texture borders and composites are dense.  Both compose
-    kernels: widths that are a power of two take compose_pow2_kernel, others compose_kernel."""
+    clipping, reflection at the texture borders and composites are dense.  Both rigid compose
+    kernels: widths that are a power of two take compose_rigid_pow2_kernel, others compose_rigid_kernel."""
     W, H = size
     g = make_gen(ofdg, W, H, mode, pool=(5, 2 * W, 2 * H))
     pool = g.pool_download_all()
@@ -420,10 +454,9 @@ def test_layer_forward_waits_for_the_oldest_batch_only(ofdg, monkeypatch):
     data_generation_layer.cpp:266-282) while the batches rendered behind it are still in flight.  One internal
     chain, so that the three batches of 128 x 512x384 samples queued ahead finish one after the other (~0.5 ms
     apart) and the state at the return of Forward is unambiguous."""
-    monkeypatch.setenv("OFDG_CHAINS", "1")
     proto = """layer { name: "d" type: "DataGeneration" top: "a" top: "b" top: "f"
       data_param { batch_size: 128 prefetch: 4 }
-      data_generation_param { mode: 7 texture_dbases: "synthetic:16:1024:768:4" sampler: counter seed: 3 } }"""
+      data_generation_param { mode: 7 texture_dbases: "synthetic:16:1024:768:4" sampler: counter seed: 3 chains: 1 } }"""
     layer = ofdg.DataGenerationLayer(proto)
     seen = []
     for _ in range(6):
@@ -627,8 +660,8 @@ def test_background_prep_zoom_beyond_the_workspace_is_reported(ofdg, oracle):
 
 @pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
 def test_background_prep_full_size_and_counter_sampler(ofdg, oracle, prep):
-    """512x384 with 1024x768 pool images; ref-sampler blueprints bit-exact, then the device counter sampler
-    (device cosf/sinf in the preparation record: <= 1 LSB on a small fraction of the pixels)."""
+    """512x384 with 1024x768 pool images; ref-sampler blueprints bit-exact, then the device counter sampler against
+    the oracle in its detmath mode (shared fp64 sin / cos, also in the preparation record): bit-exact too."""
     W, H = 512, 384
     p = ofdg.default_params(width=W, height=H, mode=5, background_prep=prep, sampler=1, seed=21, num_objects=8)
     g = ofdg.Generator(p)
@@ -644,10 +677,10 @@ def test_background_prep_full_size_and_counter_sampler(ofdg, oracle, prep):
     g.forward_counter(7, 2, i0, i1, fl)
     g.synchronize()
     tasks, bps, n = g.sample_counter(7, 2)
-    e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
-    for got_t, exp in ((i0, e0), (i1, e1)):
-        d = np.abs(got_t.cpu().numpy() - exp)
-        assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+    with oracle.detmath():  # the device builds its affines AND the preparation record's cos / sin with ofdg_detmath.h
+        e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
+    assert np.array_equal(i0.cpu().numpy(), e0) and np.array_equal(i1.cpu().numpy(), e1)
+    assert ulp_diff(fl.cpu().numpy(), ef).max() == 0
 
 
 # ---- pool images smaller than the texture they feed (the resize branch of getRandomizedCrop, DG:102-106) ----
@@ -723,10 +756,9 @@ def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle, prep)
     qc.background_prep = prep
     with oracle.detmath():
         e0, e1, ef = oracle.render(qc, ctasks, 2, cbps, cn, images[1][None])
-    # (background_prep: the preparation record's cos / sin are float on the device - at most 1 LSB on a few pixels)
-    d0, d1 = np.abs(i0.cpu().numpy() - e0), np.abs(i1.cpu().numpy() - e1)
-    assert d0.max() <= (1 if prep else 0) and d1.max() <= (1 if prep else 0), (d0.max(), d1.max())
-    assert (d0 > 0).mean() < 0.02 and (d1 > 0).mean() < 0.02
+    # (under detmath the oracle's preparation record takes the same fp64 cos / sin as the device's: bit for bit)
+    assert np.array_equal(i0.cpu().numpy(), e0) and np.array_equal(i1.cpu().numpy(), e1)
+    assert ulp_diff(fl.cpu().numpy(), ef).max() == 0
 
 
 def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_path):

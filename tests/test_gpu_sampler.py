@@ -418,8 +418,9 @@ def test_render_resident_repeats_the_last_call(ofdg):
 
 
 def test_pipeline_shape_does_not_change_the_bytes(ofdg, tmp_path):
-    """OFDG_CHAINS (number of in-order chains) and OFDG_OVERLAP=0 (everything on the caller's stream) are
-    scheduling choices: the same calls produce the same bytes as the default three chains."""
+    """ofdg_params.chains (number of in-order chains), .serial (everything on the caller's stream) and .lookahead
+    (batches prepared ahead of the call that composes them) are scheduling choices: the same calls produce the same
+    bytes as the default."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "run.py"
@@ -428,7 +429,7 @@ import importlib, sys, numpy as np, torch
 sys.path.insert(0, %r)
 ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
 W, H, B = 128, 96, 3
-g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=6, batch_size=B))
+g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, sampler=1, seed=6, batch_size=B, **eval(sys.argv[2])))
 g.pool_synthetic(3, 256, 192, 2)
 outs = [ofdg.alloc_outputs(B, H, W) for _ in range(5)]
 for k in range(5):
@@ -437,10 +438,9 @@ g.synchronize()
 np.savez(sys.argv[1], *[t.cpu().numpy() for o in outs for t in o])
 ''' % root)
     results = []
-    for env in ({}, {"OFDG_CHAINS": "1"}, {"OFDG_CHAINS": "2"}, {"OFDG_OVERLAP": "0"}):
+    for kw in ({}, {"chains": 1}, {"chains": 2}, {"serial": 1}, {"lookahead": 2}, {"chains": 2, "lookahead": 1}):
         out = tmp_path / ("out_%d.npz" % len(results))
-        e = dict(os.environ); e.update(env)
-        subprocess.run([sys.executable, str(script), str(out)], check=True, env=e, timeout=300)
+        subprocess.run([sys.executable, str(script), str(out), repr(kw)], check=True, env=dict(os.environ), timeout=300)
         results.append(np.load(out))
     for other in results[1:]:
         for k in results[0].files:

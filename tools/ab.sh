@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on ONE box: tools/ab.sh "<label>=<lib path or ->[,ENV=V...]" ...   ("-" = the in-tree libofdg.so)
 # each arm: compose alone (tools/exp_compose.py) + bench.py, repeated REPS times interleaved
-cd $GRAFT_REPO_ROOT
+: ${GRAFT_REPO_ROOT:?}; cd "$GRAFT_REPO_ROOT" || exit 1
 REPS=${REPS:-2}
 for r in $(seq $REPS); do
 for arm in "$@"; do

@@ -2,6 +2,7 @@
 # PMC passes over the compose kernel running ALONE (tools/exp_compose.py: resident batches, kernels serialised on one
 # stream).  Usage on the GPU box: bash tools/pmc_compose.sh <tag> [env assignments for the python script...]
 # Each pass is its own rocprofv3 --pmc run (no tracing domains combined with counters).
+: ${GRAFT_REPO_ROOT:?}  # (set by gpurun; refuse to run from an unknown place)
 tag=${1:-pmc}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out

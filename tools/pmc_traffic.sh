@@ -2,6 +2,7 @@
 # HBM traffic of the compose kernel for one BASELINE configuration: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over `bench.py --config N` (counter collection serialises the kernels).  Usage on the GPU box, from the repo
 # root: bash tools/pmc_traffic.sh <config> ; prints "<config> <kernel> <fetch_kb_raw> <write_kb_raw> <dur_us>"
+: ${GRAFT_REPO_ROOT:?}  # (set by gpurun; refuse to run from an unknown place)
 cfg=${1:-2}
 out=$PWD/gpurun_out/pmc_c$cfg
 mkdir -p $out

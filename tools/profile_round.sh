@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile: bench line + rocprofv3 kernel stats + HBM traffic counters (separate --pmc passes).
 # Usage (on the GPU box, from the repo root): bash tools/profile_round.sh r01
+: ${GRAFT_REPO_ROOT:?}  # (set by gpurun; refuse to run from an unknown place)
 tag=${1:-r01}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out

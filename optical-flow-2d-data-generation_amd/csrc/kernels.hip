@@ -877,6 +877,28 @@ __device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const 
   }
 }
 
+// --------------------------------------------------------------------------
+// Load helpers of the compose kernels
+// --------------------------------------------------------------------------
+// a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// ... and the loads through it name the GLOBAL address space (a pointer rebuilt from integers is generic: flat_load with a
+// 64-bit address per lane; as global memory it is global_load v, voffset32, s[base])
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const u32x2_t g_uint2;
+typedef __attribute__((address_space(1))) const uint32_t g_uint32;
+typedef __attribute__((address_space(1))) const char g_char;
+__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) {
+  asm("" : "+v"(off));  // (the offset stays a 32-bit VGPR: a select folded into a 64-bit phi would defeat the saddr form)
+  const u32x2_t v = *(g_uint2*)((g_char*)base + off);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *(g_uint32*)((g_char*)base + off); }
 // One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a 64 x 16
 // tile.  Objects are visited in painter's order (ascending ID) through the tile's object
 // bit mask; their coverage comes from the slots raster_kernel filled (valid over every
@@ -915,6 +937,80 @@ __device__ __forceinline__ Taps make_taps(float fx, float fy) {
 __device__ __forceinline__ int lerp_u8(const Taps& t, float Icc, float Inc, float Icn, float Inn) {
   const float v = Icc + t.dx * (Inc - Icc + t.dy * (Icc + Inn - Icn - Inc)) + t.dy * (Icn - Icc);
   return t.ok ? (int)(unsigned char)v : 0;
+}
+
+// Warp crops as the kernels read them: two interleaved planes of w*h float pairs - (flow x, flow y), then
+// (iflow x, iflow y) - so that a pixel's displacement is ONE 8-byte load.
+__device__ __forceinline__ float2 crop_pair(const DevCropRef& C, int plane_pair, int x, int y) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = *(OFDG_GLOBAL const f32x2*)(C.data + ((size_t)plane_pair * C.w * C.h + (size_t)y * C.w + x) * 2);
+  return make_float2(v.x, v.y);
+}
+// CImg<float>::_linear_atXY (Neumann) of both components of the forward field at once (four 8-byte taps)
+__device__ __forceinline__ float2 linear_neumann2(const DevCropRef& C, float fx, float fy) {
+  const int w = C.w, h = C.h;
+  const float nfx = fx <= 0 ? 0 : (fx >= (float)(w - 1) ? (float)(w - 1) : fx);
+  const float nfy = fy <= 0 ? 0 : (fy >= (float)(h - 1) ? (float)(h - 1) : fy);
+  const unsigned x = (unsigned)nfx, y = (unsigned)nfy;
+  const float dx = nfx - (float)x, dy = nfy - (float)y;
+  const unsigned nx = dx > 0 ? x + 1 : x, ny = dy > 0 ? y + 1 : y;
+  const float2 Icc = crop_pair(C, 0, (int)x, (int)y), Inc = crop_pair(C, 0, (int)nx, (int)y);
+  const float2 Icn = crop_pair(C, 0, (int)x, (int)ny), Inn = crop_pair(C, 0, (int)nx, (int)ny);
+  return make_float2(Icc.x + dx * (Inc.x - Icc.x + dy * (Icc.x + Inn.x - Icn.x - Inc.x)) + dy * (Icn.x - Icc.x),
+                     Icc.y + dx * (Inc.y - Icc.y + dy * (Icc.y + Inn.y - Icn.y - Inc.y)) + dy * (Icn.y - Icc.y));
+}
+// applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) for one pixel (DG:237-252, 341-345, 670-678): the
+// four texels of the TRANSFORMED texture around the displaced position t (each a bilinear filter of the source through
+// the inverse motion `inv`; Dirichlet 0 outside the tw x th texture), then CImg's fp32 lerp per channel.  While every
+// source tap of every lane that needs one lies inside the texture the eight tap pairs of a pixel are eight 8-byte loads
+// issued together; otherwise the general interpolator (reflection), sample by sample.
+template <bool kPow2>
+__device__ __forceinline__ uint32_t deform_texel(const uint32_t* __restrict__ tex_, const WarpGeom& g, const Mat& inv, const Taps& t, bool need) {
+  const uint32_t* __restrict__ tex = uniform_ptr(tex_);
+  uint32_t tap[4] = {0, 0, 0, 0};
+  int xh[4], yh[4];
+  bool valid[4];
+  RowDDA R[2];
+  bool fast = true;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ty = t.y + j;
+    const bool row_ok = need && t.ok && ty >= 0 && ty < g.th;
+    R[j] = make_row<kPow2>(inv, row_ok ? ty : 0, g.tw, g.nshift);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tx = t.x + i, k = 2 * j + i;
+      valid[k] = row_ok && tx >= 0 && tx < g.tw;
+      xh[k] = dda_at<kPow2>(R[j].x1, R[j].lx, R[j].rx, g.tw, g.nshift, valid[k] ? tx : 0) - 128;
+      yh[k] = dda_at<kPow2>(R[j].y1, R[j].ly, R[j].ry, g.tw, g.nshift, valid[k] ? tx : 0) - 128;
+      const bool in_range = (unsigned)(xh[k] >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(yh[k] >> 8) <= (unsigned)(g.th - 2);
+      fast = fast && (!valid[k] || in_range);
+    }
+  }
+  if (__ballot(!fast) == 0ull) {
+    const char* base = reinterpret_cast<const char*>(tex);
+    const char* base1 = uniform_ptr(base + (size_t)g.pitch * 4u);
+    uint2 t0[4], t1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t off = valid[k] ? ((uint32_t)(yh[k] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[k] >> 8)) * 4u : 0u;
+      t0[k] = gload2(base, off);
+      t1[k] = gload2(base1, off);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap[k] = valid[k] ? bilerp_rgb(t0[k], t1[k], (uint32_t)xh[k] & 255u, (uint32_t)yh[k] & 255u) : 0u;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap[k] = valid[k] ? sample_bilinear<kPow2>(tex, g, R[k >> 1], t.x + (k & 1)) : 0u;
+  }
+  uint32_t o = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sh = 8 * c;
+    o |= (uint32_t)lerp_u8(t, (float)((tap[0] >> sh) & 255u), (float)((tap[1] >> sh) & 255u),
+                           (float)((tap[2] >> sh) & 255u), (float)((tap[3] >> sh) & 255u)) << sh;
+  }
+  return o;
 }
 
 // Body of the compose kernel; kDeform adds the mode-9 paths (masks, textures and flow
@@ -991,42 +1087,21 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       if constexpr (kDeform) {
         if (B.deform > 0) {  // background re-sampled through its (2W x 2H, upscaled) warp crop (DG:670-678, 714-717)
           const DevCropRef C = crops[B.deform - 1];
-          const size_t cn = (size_t)C.w * C.h;
           const int X0 = x0 + W / 2, Y = y + H / 2;
 #pragma unroll 1
           for (int p = 0; p < kPx; ++p) {
             const int X = X0 + p;
-            const float iwx = C.data[2 * cn + (size_t)Y * C.w + X], iwy = C.data[3 * cn + (size_t)Y * C.w + X];
-            const Taps t = make_taps((float)X + iwx, (float)Y + iwy);
-            uint32_t tap[4] = {0, 0, 0, 0};
-            if (t.ok) {
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                const int ty = t.y + j;
-                if (ty < 0 || ty >= g.th) continue;
-                const RowDDA Rj = make_row<kPow2>(B.tex_inv, ty, g.tw, g.nshift);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  const int tx = t.x + i;
-                  if (tx >= 0 && tx < g.tw) tap[2 * j + i] = sample_bilinear<kPow2>(tex, g, Rj, tx);
-                }
-              }
-            }
-            uint32_t o = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const int sh = 8 * c;
-              o |= (uint32_t)lerp_u8(t, (float)((tap[0] >> sh) & 255u), (float)((tap[1] >> sh) & 255u),
-                                     (float)((tap[2] >> sh) & 255u), (float)((tap[3] >> sh) & 255u)) << sh;
-            }
-            px1[p] = o;
+            const float2 iw = crop_pair(C, 1, X, Y);
+            const Taps t = make_taps((float)X + iw.x, (float)Y + iw.y);
+            px1[p] = deform_texel<kPow2>(tex, g, B.tex_inv, t, true);
             // flow: + forward field at the destination (detour coordinates), Neumann
             double ix = (double)(x0 + p + W / 2) + (double)(-W), iy = by;
             xform(B.motion, ix, iy);
             ix = ix + (double)W; iy = iy + (double)H;
             if (ix >= 0 && ix < (double)(2 * W) && iy >= 0 && iy < (double)(2 * H)) {
-              fu[p] += linear_neumann(C.data, C.w, C.h, (float)ix, (float)iy);
-              fv[p] += linear_neumann(C.data + cn, C.w, C.h, (float)ix, (float)iy);
+              const float2 f = linear_neumann2(C, (float)ix, (float)iy);
+              fu[p] += f.x;
+              fv[p] += f.y;
             }
           }
         }
@@ -1059,15 +1134,13 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     // mode 9: frame-1 mask bytes (AA and thresholded) of one outline re-sampled through the
     // inverse field (MovingObjectBase::renderMasks, DG:370-386).  Taps outside the outline's
     // rasterised box read as 0 (the mask is 0 there; outside the frame: Dirichlet).
-    auto warped_mask1 = [&](int shape, const DevCropRef& C, int p, int& aa, int& na) {
+    auto warped_mask1 = [&](int shape, const DevShapeFrame& F, const DevCropRef& C, int p, int& aa, int& na) {
       aa = 0; na = 0;
       if (!inside || !has1) return;
-      const DevShapeFrame F = frames[shape * 2 + 1];
       if (F.x0 > F.x1) return;
-      const size_t cn = (size_t)C.w * C.h;
       const int x = x0 + p;
-      const float iwx = C.data[2 * cn + (size_t)y * C.w + x], iwy = C.data[3 * cn + (size_t)y * C.w + x];
-      const Taps t = make_taps((float)x + iwx, (float)y + iwy);
+      const float2 iw = crop_pair(C, 1, x, y);
+      const Taps t = make_taps((float)x + iw.x, (float)y + iw.y);
       if (!t.ok || t.x + 1 < F.x0 || t.x > F.x1 || t.y + 1 < F.y0 || t.y > F.y1) return;
       const uint8_t* c = cov + ((size_t)shape * 2 + 1) * slot_bytes;
       float va[4], vn[4];
@@ -1106,11 +1179,12 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       }
       if constexpr (kDeform) {
         if (O.deform > 0) {
+          const DevShapeFrame F1 = frames[O.first_shape * 2 + 1];  // (once per visit, not once per pixel)
           const DevCropRef C = crops[O.deform - 1];
 #pragma unroll 1
           for (int p = 0; p < kPx; ++p) {
             int aa, na;
-            warped_mask1(O.first_shape, C, p, aa, na);
+            warped_mask1(O.first_shape, F1, C, p, aa, na);
             m1[p] = dm.use_aa ? aa : na;
           }
         }
@@ -1123,10 +1197,10 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
       for (int k = 0; k < O.n_shapes; ++k) {
         const uint8_t* c = cov + (size_t)(O.first_shape + k) * 2 * slot_bytes;
         uint32_t c0w = 0, c1w = 0;
+        const DevShapeFrame F0 = frames[(O.first_shape + k) * 2], F1 = frames[(O.first_shape + k) * 2 + 1];
         if (inside) {
           // a component's coverage exists only in the 64 x 8 blocks its own box touches
           const int by0c = ty0 + (tid >> 7) * kBandRows;
-          const DevShapeFrame F0 = frames[(O.first_shape + k) * 2], F1 = frames[(O.first_shape + k) * 2 + 1];
           int d1 = 0;
           if constexpr (kDeform) { if (O.deform > 0) d1 = (int)ceilf(__uint_as_float(*crops[O.deform - 1].max_bits)) + 2; }
           const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
@@ -1143,7 +1217,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
           const int vn0 = c0 >= 128 ? 255 : 0;
           int vn1 = c1 >= 128 ? 255 : 0;
           if constexpr (kDeform) {
-            if (O.deform > 0) warped_mask1(O.first_shape + k, crops[O.deform - 1], p, va1, vn1);  // components warp individually
+            if (O.deform > 0) warped_mask1(O.first_shape + k, F1, crops[O.deform - 1], p, va1, vn1);  // components warp individually
           }
           if (additive) {
             ua0[p] = comp_add(ua0[p], va0); ua1[p] = comp_add(ua1[p], va1);
@@ -1182,35 +1256,15 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     if constexpr (kDeform) {
       if (any1 && deform_tex) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
         const DevCropRef C = crops[O.deform - 1];
-        const size_t cn = (size_t)C.w * C.h;
 #pragma unroll 1
         for (int p = 0; p < kPx; ++p) {
-          if (!((m1w >> (8 * p)) & 255u)) continue;
+          const bool need = ((m1w >> (8 * p)) & 255u) != 0u;
+          if (__ballot(need) == 0ull) continue;
           const int x = x0 + p;
-          const float iwx = C.data[2 * cn + (size_t)y * C.w + x], iwy = C.data[3 * cn + (size_t)y * C.w + x];
-          const Taps t = make_taps((float)x + iwx, (float)y + iwy);
-          uint32_t tap[4] = {0, 0, 0, 0};
-          if (t.ok) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int ty = t.y + j;
-              if (ty < 0 || ty >= H) continue;
-              const RowDDA Rj = make_row<kPow2>(O.tex_inv, ty, W, g.nshift);
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const int tx = t.x + i;
-                if (tx >= 0 && tx < W) tap[2 * j + i] = sample_bilinear<kPow2>(tex, g, Rj, tx);
-              }
-            }
-          }
-          uint32_t o = 0;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int sh = 8 * c;
-            o |= (uint32_t)lerp_u8(t, (float)((tap[0] >> sh) & 255u), (float)((tap[1] >> sh) & 255u),
-                                   (float)((tap[2] >> sh) & 255u), (float)((tap[3] >> sh) & 255u)) << sh;
-          }
-          t1[p] = o;
+          const float2 iw = need ? crop_pair(C, 1, x, y) : make_float2(0.f, 0.f);
+          const Taps t = make_taps((float)x + iw.x, (float)y + iw.y);
+          const uint32_t o = deform_texel<kPow2>(tex, g, O.tex_inv, t, need);
+          if (need) t1[p] = o;
         }
       }
     }
@@ -1235,9 +1289,9 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
           fv[p] = (float)(iy - (double)save_y);
           if constexpr (kDeform) {
             if (O.deform > 0 && ix >= 0 && ix < (double)W && iy >= 0 && iy < (double)H) {  // DG:403-406
-              const DevCropRef C = crops[O.deform - 1];
-              fu[p] += linear_neumann(C.data, C.w, C.h, (float)ix, (float)iy);
-              fv[p] += linear_neumann(C.data + (size_t)C.w * C.h, C.w, C.h, (float)ix, (float)iy);
+              const float2 f = linear_neumann2(crops[O.deform - 1], (float)ix, (float)iy);
+              fu[p] += f.x;
+              fv[p] += f.y;
             }
           }
         }
@@ -1309,28 +1363,6 @@ __global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
   compose_body<true, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
 }
 
-// --------------------------------------------------------------------------
-// Load helpers of the rigid-mode compose kernels
-// --------------------------------------------------------------------------
-// a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
-template <class T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-// ... and the loads through it name the GLOBAL address space (a pointer rebuilt from integers is generic: flat_load with a
-// 64-bit address per lane; as global memory it is global_load v, voffset32, s[base])
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const u32x2_t g_uint2;
-typedef __attribute__((address_space(1))) const uint32_t g_uint32;
-typedef __attribute__((address_space(1))) const char g_char;
-__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) {
-  asm("" : "+v"(off));  // (the offset stays a 32-bit VGPR: a select folded into a 64-bit phi would defeat the saddr form)
-  const u32x2_t v = *(g_uint2*)((g_char*)base + off);
-  return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *(g_uint32*)((g_char*)base + off); }
 struct Taps4 {
   uint2 t0[kPx], t1[kPx];  // texel pairs of the two rows (mode 2: t0[p].x = the finished pixel)
   uint32_t xf, yf;         // fractions, byte p = pixel p
@@ -1837,7 +1869,7 @@ __global__ __launch_bounds__(256) void wf_crop_kernel(const float* __restrict__ 
     const size_t n = (size_t)S * S, cn = (size_t)cw * ch;
     for (int f = 0; f < 4; ++f) {
       const float v = field[f * n + (size_t)(y0 + y) * S + (x0 + x)];
-      crop[f * cn + i] = v;
+      crop[(size_t)(f >> 1) * 2 * cn + 2 * (size_t)i + (f & 1)] = v;  // interleaved pairs: (flow x, flow y), (iflow x, iflow y)
       if (f >= 2 && v == v) m = fmaxf(m, fabsf(v));
     }
   }
@@ -1862,12 +1894,12 @@ __global__ __launch_bounds__(256) void wf_resize2_kernel(const float* __restrict
     const int y1 = yi[y], y2 = min(y1 + 1, ch - 1);
     const double ax = xa[x], ay = ya[y];
     for (int f = 0; f < 4; ++f) {
-      const float* p = crop + f * cn;
-      const float r1 = (float)((1 - ax) * (double)p[(size_t)y1 * cw + x1] + ax * (double)p[(size_t)y1 * cw + x2]);
-      const float r2 = (float)((1 - ax) * (double)p[(size_t)y2 * cw + x1] + ax * (double)p[(size_t)y2 * cw + x2]);
+      const float* p = crop + (size_t)(f >> 1) * 2 * cn + (f & 1);  // (interleaved pairs, as wf_crop_kernel writes them)
+      const float r1 = (float)((1 - ax) * (double)p[2 * ((size_t)y1 * cw + x1)] + ax * (double)p[2 * ((size_t)y1 * cw + x2)]);
+      const float r2 = (float)((1 - ax) * (double)p[2 * ((size_t)y2 * cw + x1)] + ax * (double)p[2 * ((size_t)y2 * cw + x2)]);
       const float v = (float)((1 - ay) * (double)r1 + ay * (double)r2);
       const float v2 = (float)((double)v * 2.);
-      out[f * on + i] = v2;
+      out[(size_t)(f >> 1) * 2 * on + 2 * (size_t)i + (f & 1)] = v2;
       if (f >= 2 && v2 == v2) m = fmaxf(m, fabsf(v2));
     }
   }

@@ -155,7 +155,7 @@ struct ofdg_ctx {
   DevBuf<int> d_cs_nobj;
   long long next_index = 0;  // next global sample index of this rank's stream
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
-  float* d_warp = nullptr;         // [n_crops][4][(H+1)][(W+1)]
+  float* d_warp = nullptr;         // [n_crops][2 pairs][(H+1)][(W+1)][2]: (flow x, flow y), (iflow x, iflow y) interleaved
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
   // counter sampler, mode 9: every crop as the kernels see it, [k] the crop itself (foreground), [n_crops + k] its
   // 2W x 2H upscaled copy (backgrounds); built once per set of crops
@@ -1516,7 +1516,16 @@ int ofdg_warp_upload(ofdg_ctx* c, const float* crops, int n) {
   int rc = warp_alloc(c, n);
   if (rc != OFDG_OK) return rc;
   const size_t plane = (size_t)(c->prm.width + 1) * (c->prm.height + 1), crop_floats = 4 * plane;
-  HIP_OK(c, hipMemcpy(c->d_warp, crops, (size_t)n * crop_floats * sizeof(float), hipMemcpyHostToDevice));
+  {  // the kernels read a crop as two planes of interleaved pairs: (flow x, flow y), (iflow x, iflow y)
+    std::vector<float> il((size_t)n * crop_floats);
+    for (int k = 0; k < n; ++k)
+      for (int f = 0; f < 4; ++f) {
+        const float* src = crops + (size_t)k * crop_floats + (size_t)f * plane;
+        float* dst = il.data() + (size_t)k * crop_floats + (size_t)(f >> 1) * 2 * plane + (f & 1);
+        for (size_t i = 0; i < plane; ++i) dst[2 * i] = src[i];
+      }
+    HIP_OK(c, hipMemcpy(c->d_warp, il.data(), il.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   std::vector<unsigned> mx(n, 0u);
   for (int k = 0; k < n; ++k) {
     float m = 0.f;
@@ -1540,7 +1549,13 @@ int ofdg_warp_download(ofdg_ctx* c, int index, float* crop) {
   if (!c || !crop || index < 0 || index >= c->crop_server.n_crops) return OFDG_EINVAL;
   const size_t crop_floats = (size_t)4 * (c->prm.width + 1) * (c->prm.height + 1);
   HIP_OK(c, hipDeviceSynchronize());
-  HIP_OK(c, hipMemcpy(crop, c->d_warp + (size_t)index * crop_floats, crop_floats * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<float> il(crop_floats);
+  HIP_OK(c, hipMemcpy(il.data(), c->d_warp + (size_t)index * crop_floats, crop_floats * sizeof(float), hipMemcpyDeviceToHost));
+  const size_t plane = crop_floats / 4;  // (device layout: interleaved pairs; the API's: four planes)
+  for (int f = 0; f < 4; ++f) {
+    const float* src = il.data() + (size_t)(f >> 1) * 2 * plane + (f & 1);
+    for (size_t i = 0; i < plane; ++i) crop[(size_t)f * plane + i] = src[2 * i];
+  }
   return OFDG_OK;
 }
 

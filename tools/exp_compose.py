@@ -9,6 +9,8 @@ W, H, MODE, B = 512, 384, int(os.environ.get("MODE", "5")), 32
 NOBJ = int(os.environ.get("NOBJ", "16"))
 g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=MODE, num_objects=NOBJ, serial=1))  # one kernel after the other on the caller's stream
 g.pool_synthetic(int(os.environ.get("POOLN", "1000")), int(os.environ.get("POOLW", "1024")), int(os.environ.get("POOLH", "768")), 2024)
+if MODE == 9:
+    g.warp_generate(2, 2024)
 hs = ofdg.HostSampler(MODE, W, H, NOBJ)
 st = torch.cuda.current_stream().cuda_stream
 NS = 8

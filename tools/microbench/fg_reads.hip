@@ -6,6 +6,9 @@
 //   independent   issued together with the background reads
 //   dependent     issued after the background reads have returned (compose: coverage -> ballot -> taps)
 //   warm          the object images come from the first 64 pool images (Infinity-Cache resident)
+// Round 3: LAYOUT = how a pool image is laid out (0 row-major, 1 tiles of 16 x 4 texels, 2 tiles of 8 x 8 texels: 256 B each,
+// tiles in row-major order) and ROT = the object windows are read along a line rotated by 30 degrees (real objects carry
+// any rotation; the background never more than 10 degrees).
 // hipcc --offload-arch=gfx950 -O3 fg_reads.hip -o fg_reads
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,6 +23,81 @@ __device__ __forceinline__ uint32_t hash32(uint32_t h) { h ^= h >> 16; h *= 0x85
 
 // MODE 0: no visits; 1: independent; 2: dependent; 3: independent, the window as two wide row loads (6 rows x 272 B:
 // what staging the window in LDS would issue); WARM: object images from the first 64
+// byte offset of texel (x, y) inside an image
+template <int LAYOUT>
+__device__ __forceinline__ size_t texel_at(int x, int y) {
+  if (LAYOUT == 0) return ((size_t)y * PW + x) * 4;
+  if (LAYOUT == 1) return ((size_t)((y >> 2) * (PW / 16) + (x >> 4)) * 64 + ((y & 3) * 16 + (x & 15))) * 4;
+  return ((size_t)((y >> 3) * (PW / 8) + (x >> 3)) * 64 + ((y & 7) * 8 + (x & 7))) * 4;
+}
+// compose's memory operations on a LAYOUT pool: background texels of both frames (4 px per lane), stores, and object
+// windows (frame 0: the lane's 4 texels; frame 1: two texel pairs on two rows per pixel, along a rotated line if ROT)
+template <int LAYOUT, bool ROT, bool WARM, bool VISITS>
+__global__ __launch_bounds__(64) void layout_kernel(const uint32_t* __restrict__ pool_, float* __restrict__ out, int salt) {
+  const char* pool = reinterpret_cast<const char*>(pool_);
+  constexpr int per_row = W / 64, per_sample = per_row * (H / 4);
+  int wg = blockIdx.x;
+  { const int xcd = wg & 7, slot = wg >> 3; wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31); }
+  const int s = wg / per_sample, t = wg - s * per_sample;
+  const int lane = threadIdx.x;
+  const int x0 = (t % per_row) * 64 + (lane & 15) * 4, y = (t / per_row) * 4 + (lane >> 4);
+  const uint32_t img = (hash32((uint32_t)s * 2654435761u + (uint32_t)salt * 40503u) >> 7) % NPOOL;
+  const char* tex = pool + (size_t)img * PW * PH * 4;
+  const uint32_t cell = hash32((uint32_t)(s * 131 + (t % per_row) * 17 + (t / per_row) / 12) * 2246822519u + (uint32_t)salt);
+  const int visits = !VISITS ? 0 : ((cell % 100u) < 38u ? ((cell >> 8) % 3u == 0 ? 2 : 1) : 0);  // wave-uniform
+  // background: frame 0 = 4 consecutive texels (16 B: inside one tile for both tilings), frame 1 = taps shifted by (12.x, 9.x)
+  const uint4 a = *reinterpret_cast<const uint4*>(tex + texel_at<LAYOUT>(x0 + PW / 4, y + PH / 4));
+  uint2 bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bt[k] = *reinterpret_cast<const uint2*>(tex + texel_at<LAYOUT>(x0 + PW / 4 + 12 + (k & 3), y + PH / 4 + 9 + (k >> 2)));
+  uint32_t acc = 0;
+  for (int v = 0; v < visits; ++v) {
+    const uint32_t oimg = (hash32(cell + 77u * (uint32_t)v) >> 5) % (WARM ? 64u : (uint32_t)NPOOL);
+    const char* ot = pool + (size_t)oimg * PW * PH * 4;
+    const int ox = PW / 2 - W / 2, oy = PH / 2 - H / 2;
+    const uint4 q = *reinterpret_cast<const uint4*>(ot + texel_at<LAYOUT>(ox + x0, oy + y));
+    uint2 tp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int tx = x0 + 2 + (k & 3), ty = y + 1 + (k >> 2);
+      if (ROT) {  // rotate about the frame centre by 30 degrees (integer arithmetic: 887 / 1024, 512 / 1024)
+        const int dx = tx - W / 2, dy = ty - H / 2;
+        tx = W / 2 + ((887 * dx - 512 * dy) >> 10); ty = H / 2 + ((512 * dx + 887 * dy) >> 10);
+        tx = min(max(tx, -ox), PW - ox - 2); ty = min(max(ty, -oy), PH - oy - 1);
+      }
+      tp[k] = *reinterpret_cast<const uint2*>(ot + texel_at<LAYOUT>(ox + tx, oy + ty));
+    }
+    acc ^= q.x + q.y + q.z + q.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += tp[k].x * 3u + tp[k].y;
+    asm volatile("" : "+v"(acc));
+  }
+  uint4 b = make_uint4(bt[0].x ^ bt[4].y, bt[1].x ^ bt[5].y, bt[2].x ^ bt[6].y, bt[3].x ^ bt[7].y);
+  b.x ^= acc;
+  const size_t plane = (size_t)W * H, o = (size_t)y * W + x0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const uint32_t sh = 8 * (p % 3);
+    const uint4 q = (p & 1) ? b : a;
+    f32x4 vv = {(float)((q.x >> sh) & 255u), (float)((q.y >> sh) & 255u), (float)((q.z >> sh) & 255u), (float)((q.w >> sh) & 255u)};
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(out + ((size_t)s * 8 + p) * plane + o));
+  }
+}
+template <int LAYOUT, bool ROT, bool WARM, bool VISITS>
+static float run_layout(const uint32_t* pool, float* out, int reps) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int grid = B * (W / 64) * (H / 4);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((layout_kernel<LAYOUT, ROT, WARM, VISITS>), dim3(grid), dim3(64), 0, 0, pool, out, i);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((layout_kernel<LAYOUT, ROT, WARM, VISITS>), dim3(grid), dim3(64), 0, 0, pool, out, 5 + i);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
 template <int MODE, bool WARM, bool STORES, int BPT>
 __global__ __launch_bounds__(64) void fg_kernel(const uint32_t* __restrict__ pool_, float* __restrict__ out, int salt) {
   const char* pool = reinterpret_cast<const char*>(pool_);
@@ -112,6 +190,13 @@ int main() {
   CK(hipMemset(pool, 0x5A, pool_bytes));
   CK(hipDeviceSynchronize());
   for (int round = 0; round < 2; ++round) {
+    printf("pool layout (stores + background texels and taps; visits cold / cold rotated 30 deg / warm rotated):\n");
+    printf("  row-major      : no visits %6.1f us | %6.1f / %6.1f / %6.1f\n", run_layout<0, false, false, false>(pool, out, 100),
+           run_layout<0, false, false, true>(pool, out, 100), run_layout<0, true, false, true>(pool, out, 100), run_layout<0, true, true, true>(pool, out, 100));
+    printf("  tiles 16 x 4   : no visits %6.1f us | %6.1f / %6.1f / %6.1f\n", run_layout<1, false, false, false>(pool, out, 100),
+           run_layout<1, false, false, true>(pool, out, 100), run_layout<1, true, false, true>(pool, out, 100), run_layout<1, true, true, true>(pool, out, 100));
+    printf("  tiles 8 x 8    : no visits %6.1f us | %6.1f / %6.1f / %6.1f\n", run_layout<2, false, false, false>(pool, out, 100),
+           run_layout<2, false, false, true>(pool, out, 100), run_layout<2, true, false, true>(pool, out, 100), run_layout<2, true, true, true>(pool, out, 100));
     printf("with stores : no visits %6.1f us | independent cold %6.1f  warm %6.1f | dependent cold %6.1f  warm %6.1f\n",
            run<0, false, true>(pool, out, 100), run<1, false, true>(pool, out, 100), run<1, true, true>(pool, out, 100),
            run<2, false, true>(pool, out, 100), run<2, true, true>(pool, out, 100));

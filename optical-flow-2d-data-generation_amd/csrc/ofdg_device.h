@@ -133,7 +133,7 @@ struct TexSource {
 #endif
 // One served warp crop as the kernels see it (mode 9).
 struct DevCropRef {
-  OFDG_GLOBAL const float* data;         // 4 planes of w*h floats: flow x, flow y, iflow x, iflow y
+  OFDG_GLOBAL const float* data;         // two planes of w*h float PAIRS: (flow x, flow y), then (iflow x, iflow y)
   OFDG_GLOBAL const unsigned* max_bits;  // float bits of max |iflow| over the crop (NaNs ignored)
   int32_t w, h;
 };

@@ -2029,7 +2029,7 @@ __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __
     const int j = cy0 + jj, i = cx0 + ii;
     const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
     const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-    Cs[(size_t)j * p.cw + i] = bgprep_rot_sample(p, xc, yc);
+    Cs[(uint32_t)(j * p.cw + i)] = bgprep_rot_sample(p, xc, yc);
   }
 }
 // a / d correctly rounded for operands that need none of the IEEE division's range handling (here 0 <= a < 2^31,
@@ -2048,6 +2048,10 @@ __device__ __forceinline__ float div_rn(float a, const UniformDivisor& u) {
 // one axis of CImg's linear get_resize on BGRX texels: destination pixel k of a line whose source texels are texel(j),
 // j < n; sdim = destination length.  Enlarging: (T)((1 - a) * v1 + a * v2) in double; shrinking: moving average over the
 // n * sdim grid in float, / n, truncated; same length: copy.
+// (double)u for u < 2^32 without v_cvt_f64_u32 (9 issue cycles against 5 for an addition, tools/microbench/f64_rates.hip):
+// the bits of 2^52 + u, minus 2^52 - exact
+__device__ __forceinline__ double u32_to_double(uint32_t u) { return __hiloint2double(0x43300000, (int)u) - 4503599627370496.0; }
+// `at` / `alpha`: the enlarging tables' rows of THIS source length (the caller adds n * sdim once: uniform per sample)
 template <class Texel>
 __device__ __forceinline__ uint32_t cimg_resize_texel(int n, int sdim, int k, const uint16_t* __restrict__ at, const double* __restrict__ alpha,
                                                       Texel texel) {
@@ -2055,13 +2059,13 @@ __device__ __forceinline__ uint32_t cimg_resize_texel(int n, int sdim, int k, co
   if (sdim == n) {
     out = texel(k);
   } else if (sdim > n) {
-    const int a0 = at[(size_t)n * sdim + k];
-    const double al = alpha[(size_t)n * sdim + k];
+    const int a0 = at[(uint32_t)k];
+    const double al = alpha[(uint32_t)k], al1 = 1 - al;
     const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double v1 = (double)((t1 >> (8 * c)) & 255u), v2 = (double)((t2 >> (8 * c)) & 255u);
-      out |= (uint32_t)(unsigned char)((1 - al) * v1 + al * v2) << (8 * c);
+      const double v1 = u32_to_double((t1 >> (8 * c)) & 255u), v2 = u32_to_double((t2 >> (8 * c)) & 255u);
+      out |= (uint32_t)(unsigned char)(al1 * v1 + al * v2) << (8 * c);
     }
   } else {
     float acc[3] = {0.f, 0.f, 0.f};
@@ -2096,6 +2100,11 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
   const int runs = (rh_ + kResizeRun - 1) / kResizeRun;
   const uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
   uint32_t* Bs = B + (size_t)s * TW * TH;
+  // the enlarging tables' rows of this sample's source lengths (entry [n * S + x]: uniform bases, 32-bit indices below)
+  const uint16_t* at_x = T.at_x + (size_t)p.cw * TW;
+  const double* alpha_x = T.alpha_x + (size_t)p.cw * TW;
+  const uint16_t* at_y = T.at_y + (size_t)p.ch * TH;
+  const double* alpha_y = T.alpha_y + (size_t)p.ch * TH;
   const float inv_rw = 1.0f / (float)rw_;
   for (int k = blockIdx.x * blockDim.x + tid; k < runs * rw_; k += gridDim.x * blockDim.x) {
     int rr = (int)((float)k * inv_rw);  // k / rw_ (k < 2^22: the float quotient is off by one at most)
@@ -2103,7 +2112,7 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
     if (xo < 0) { --rr; xo += rw_; } else if (xo >= rw_) { ++rr; xo -= rw_; }
     const int x = p.rx0 + xo, y0 = p.ry0 + rr * kResizeRun, y1 = min(y0 + kResizeRun - 1, p.ry1);
     auto c_row = [&](int j) {  // M(x, j)
-      return cimg_resize_texel(p.cw, TW, x, T.at_x, T.alpha_x, [&](int i) { return Cs[(size_t)j * p.cw + i]; });
+      return cimg_resize_texel(p.cw, TW, x, at_x, alpha_x, [&](int i) { return Cs[(uint32_t)(j * p.cw + i)]; });
     };
     int jlo, jhi;
     cimg_resize_range(p.ch, TH, y0, y1, T.at_y, &jlo, &jhi);
@@ -2113,9 +2122,9 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
         if (jlo + m <= jhi) s_m[m][tid] = c_row(jlo + m);
 #pragma unroll
       for (int r = 0; r < kResizeRun; ++r)
-        if (y0 + r <= y1) Bs[(size_t)(y0 + r) * TW + x] = cimg_resize_texel(p.ch, TH, y0 + r, T.at_y, T.alpha_y, [&](int j) { return s_m[j - jlo][tid]; });
+        if (y0 + r <= y1) Bs[(uint32_t)((y0 + r) * TW + x)] = cimg_resize_texel(p.ch, TH, y0 + r, at_y, alpha_y, [&](int j) { return s_m[j - jlo][tid]; });
     } else {  // (a crop beyond 4/3 of the texture is refused before it gets here; kept for safety)
-      for (int y = y0; y <= y1; ++y) Bs[(size_t)y * TW + x] = cimg_resize_texel(p.ch, TH, y, T.at_y, T.alpha_y, c_row);
+      for (int y = y0; y <= y1; ++y) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel(p.ch, TH, y, at_y, alpha_y, c_row);
     }
   }
 }

@@ -540,6 +540,23 @@ def test_mode9_field_generation_equals_oracle(ofdg, oracle):
     assert np.isnan(ref).any() or np.abs(ref).max() > 1.0
 
 
+def test_mode9_field_generation_stays_close_to_the_libm_oracle(ofdg, oracle):
+    """The device's fields take ofdg_det_expf (the fp64 exponential rounded once) for BOTH samplers; the reference takes
+    libm's expf (WarpFields.cpp:101-112).  Against the oracle in its default - libm - arithmetic the device's crops are not
+    bit-equal, but they are the same fields: the same NaN pattern up to a handful of border texels and displacements
+    that agree to a small fraction of a pixel."""
+    W, H = 128, 96
+    g = make_gen(ofdg, W, H, 9, pool=(2, 256, 192))
+    g.warp_generate(1, seed=11)
+    ref = oracle.warp_crops(W, H, seed=11)          # libm expf
+    got = np.stack([g.warp_download(k) for k in range(len(ref))])
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert (nan_g != nan_r).mean() < 1e-3, (nan_g != nan_r).mean()
+    both = ~nan_g & ~nan_r
+    d = np.abs(got[both] - ref[both])
+    assert d.max() < 0.05 and d.mean() < 1e-4, (d.max(), d.mean())
+
+
 def test_mode9_full_size_device_generated_fields_match_oracle(ofdg, oracle):
     """BASELINE config 3 at its own size (mode 9, 512 x 384): the 1536^2 big field generated on the device equals the
     oracle's bit for bit (all 40 crops), and samples rendered with the DEVICE-generated crops (downloaded and handed

@@ -1,17 +1,41 @@
 #!/bin/bash
-# Round profile: bench line + rocprofv3 kernel stats + HBM traffic counters (separate --pmc passes).
-# Usage (on the GPU box, from the repo root): bash tools/profile_round.sh r01
+# Round profile, everything the bench line's numbers are backed by:
+#   bench line (default = config 2, 2000 steps, with cpu_baseline and reference_equivalent), the driver's form of it
+#   (--steps 20 --warmup 5), the other BASELINE configurations, rocprofv3 kernel statistics of the default command, and
+#   HBM traffic of the dominant kernel from SEPARATE --pmc FETCH_SIZE / WRITE_SIZE passes (configs 2 and 3).
+# Usage (on the GPU box): bash tools/profile_round.sh r03      -> gpurun_out/<tag>/
 : ${GRAFT_REPO_ROOT:?}  # (set by gpurun; refuse to run from an unknown place)
-tag=${1:-r01}
-out=$PWD/gpurun_out/$tag
+cd "$GRAFT_REPO_ROOT" || exit 1
+tag=${1:-r03}
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
-python3 bench.py > $out/bench_line.json 2> $out/bench_stderr.txt
+echo "[bench] default"; timeout -k 10 500 python3 bench.py > $out/bench_line.json 2> $out/bench_stderr.txt
+echo "[bench] driver-like"; timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_line_driver_like_20_steps.json 2>> $out/bench_stderr.txt
+for cfg in 1 3 4 5; do
+  echo "[bench] config $cfg"; timeout -k 10 400 python3 bench.py --config $cfg > $out/bench_line_config$cfg.json 2>> $out/bench_stderr.txt
+done
+echo "[bench] background_prep"; timeout -k 10 300 python3 bench.py --background-prep --no-cpu-baseline > $out/bench_line_config2_background_prep.json 2>> $out/bench_stderr.txt
+echo "[bench] resident"; timeout -k 10 300 python3 bench.py --sampler resident --no-cpu-baseline --no-reference-equivalent > $out/bench_line_config2_resident.json 2>> $out/bench_stderr.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/bench_line_profiled.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 60 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 60 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
+echo "[rocprofv3] kernel trace"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-reference-equivalent > $out/bench_line_under_rocprof.json 2>/dev/null
+for cfg in 2 3; do
+  echo "[rocprofv3] pmc config $cfg"
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-reference-equivalent --steps 60 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-reference-equivalent --steps 60 > /dev/null 2>&1
+done
+cd "$GRAFT_REPO_ROOT"
 python3 tools/kstats.py $out/trace > $out/kernel_stats.txt
-python3 tools/pmcstats.py $out/pmc_fetch > $out/pmc_fetch_size.txt
-python3 tools/pmcstats.py $out/pmc_write > $out/pmc_write_size.txt
-tail -n 12 $out/kernel_stats.txt; cat $out/pmc_fetch_size.txt $out/pmc_write_size.txt | grep -A3 compose; cat $out/bench_line.json
+cp $(ls $out/trace/*kernel_stats.csv $out/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats.csv 2>/dev/null
+for cfg in 2 3; do
+  python3 tools/pmcstats.py $out/pmc_fetch_c$cfg > $out/pmc_fetch_size_config$cfg.txt
+  python3 tools/pmcstats.py $out/pmc_write_c$cfg > $out/pmc_write_size_config$cfg.txt
+done
+rm -rf $out/trace $out/pmc_fetch_c* $out/pmc_write_c*
+tail -n 12 $out/kernel_stats.txt; grep -A3 compose $out/pmc_fetch_size_config2.txt $out/pmc_write_size_config2.txt; python3 -c "
+import json,glob
+for f in sorted(glob.glob('$out/bench_line*.json')):
+    try: d=json.load(open(f))
+    except Exception as e: print(f, 'unreadable', e); continue
+    r=d.get('reference_equivalent') or {}
+    print('%-55s %9.0f samples/s %7.1f us/step frac %.3f ref-eq %s' % (f.split('/')[-1], d['value'], d['ms_per_step']*1e3, d['roofline']['whole_step_frac'], ('%.0f' % r['value']) if r else '-'))"

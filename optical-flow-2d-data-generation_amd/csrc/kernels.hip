@@ -692,6 +692,28 @@ __device__ __forceinline__ int comp_sub(int u, int v) {
   return (int)(unsigned char)__fmul_rn(255.f, __fmul_rn(fu, __fsub_rn(1.f, fv)));
 }
 
+// --------------------------------------------------------------------------
+// Load helpers of the texture warps
+// --------------------------------------------------------------------------
+// a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// ... and the loads through it name the GLOBAL address space (a pointer rebuilt from integers is generic: flat_load with a
+// 64-bit address per lane; as global memory it is global_load v, voffset32, s[base])
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const u32x2_t g_uint2;
+typedef __attribute__((address_space(1))) const uint32_t g_uint32;
+typedef __attribute__((address_space(1))) const char g_char;
+__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) {
+  asm("" : "+v"(off));  // (the offset stays a 32-bit VGPR: a select folded into a 64-bit phi would defeat the saddr form)
+  const u32x2_t v = *(g_uint2*)((g_char*)base + off);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *(g_uint32*)((g_char*)base + off); }
 // span_interpolator_linear::begin + dda2_line_interpolator for one output row.
 struct RowDDA {
   int x1, lx, rx;  // start, lft, rem (rem in [1, n])
@@ -877,28 +899,6 @@ __device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const 
   }
 }
 
-// --------------------------------------------------------------------------
-// Load helpers of the compose kernels
-// --------------------------------------------------------------------------
-// a wave-uniform pointer the compiler can see is uniform (SGPR pair): loads take it as scalar base + 32-bit lane offset
-template <class T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-// ... and the loads through it name the GLOBAL address space (a pointer rebuilt from integers is generic: flat_load with a
-// 64-bit address per lane; as global memory it is global_load v, voffset32, s[base])
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const u32x2_t g_uint2;
-typedef __attribute__((address_space(1))) const uint32_t g_uint32;
-typedef __attribute__((address_space(1))) const char g_char;
-__device__ __forceinline__ uint2 gload2(const char* base, uint32_t off) {
-  asm("" : "+v"(off));  // (the offset stays a 32-bit VGPR: a select folded into a 64-bit phi would defeat the saddr form)
-  const u32x2_t v = *(g_uint2*)((g_char*)base + off);
-  return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ uint32_t gload1(const char* base, uint32_t off) { return *(g_uint32*)((g_char*)base + off); }
 // One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a 64 x 16
 // tile.  Objects are visited in painter's order (ascending ID) through the tile's object
 // bit mask; their coverage comes from the slots raster_kernel filled (valid over every

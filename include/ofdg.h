@@ -264,7 +264,7 @@ int ofdg_poll_errors(ofdg_ctx* ctx);
 /* Generate n_fields big fields (side 3*max(W,H)) on the device from seeded displacer
  * lists (the reference seeds from std::random_device) and cut them into (W+1)x(H+1)
  * crops; crops are then served like CropGenerator::get_crop (each 3 times, in order).
- * The Gaussian supports' exponential (WF:101-112) is ofdg_det_expf (include/ofdg_detmath.h: the fp64 exponential rounded
+ * The Gaussian supports' exponential (WF:101-112) is the det_expf of include/ofdg_detmath.h (the fp64 exponential rounded
  * once) for BOTH samplers, not libm's expf: the fields are reproducible bit for bit on any device and in the oracle's detmath
  * mode, and agree with a libm evaluation to a small fraction of a pixel (tests/test_gpu_parity.py). */
 int ofdg_warp_generate(ofdg_ctx* ctx, int n_fields, uint32_t seed);

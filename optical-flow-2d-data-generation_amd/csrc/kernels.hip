@@ -2009,7 +2009,51 @@ __device__ __forceinline__ bool bgprep_region(const DevBgPrep& p, const DevResiz
   cimg_resize_range(p.cw, TW, p.rx0, p.rx1, T.at_x, cx0, cx1);
   return true;
 }
-// C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y
+// Two horizontally adjacent texels of C at once: R(x, y) of bgprep_rot_sample for (xc0, yc) and (xc1, yc), the same
+// strict-fp32 operations per texel, evaluated on float pairs (v_pk_mul_f32 / v_pk_add_f32: one instruction for both), and
+// - when no lane of the wave leaves the image (no mirroring, no clamping: the usual case, the rotation is a few degrees) -
+// without the wrap logic.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 bgprep_rot_sample2(const DevBgPrep& p, float xc0, float xc1, float yc, bool second) {
+  OFDG_GLOBAL const uint32_t* img = (OFDG_GLOBAL const uint32_t*)p.image_addr;
+  const int pw = p.pw, ph = p.ph;
+  const f32x2 xc = {xc0, xc1};
+  // mx = (w2 + xc * ca) + yc * sa;  my = (h2 - xc * sa) + yc * ca   (element-wise: exactly the scalar sequence)
+  const f32x2 mx = (f32x2{p.w2, p.w2} + xc * f32x2{p.ca, p.ca}) + f32x2{__fmul_rn(yc, p.sa), __fmul_rn(yc, p.sa)};
+  const f32x2 my = (f32x2{p.h2, p.h2} - xc * f32x2{p.sa, p.sa}) + f32x2{__fmul_rn(yc, p.ca), __fmul_rn(yc, p.ca)};
+  // inside [0, pw - 1) x [0, ph - 1): mod, mirror and the Neumann clamp are identities, nx = x + 1 exists
+  const bool in0 = mx.x >= 0.f && mx.x < (float)(pw - 1) && my.x >= 0.f && my.x < (float)(ph - 1);
+  const bool in1 = !second || (mx.y >= 0.f && mx.y < (float)(pw - 1) && my.y >= 0.f && my.y < (float)(ph - 1));
+  const bool shift_plain = p.shx >= 0 && p.shx <= pw && p.shy >= 0 && p.shy <= ph;  // (uniform)
+  if (__ballot(!(in0 && in1)) != 0ull || !shift_plain)
+    return make_uint2(bgprep_rot_sample(p, xc0, yc), second ? bgprep_rot_sample(p, xc1, yc) : 0u);
+  const int x0i = (int)mx.x, y0i = (int)my.x, x1i = (int)mx.y, y1i = (int)my.y;
+  const f32x2 dx = mx - f32x2{(float)x0i, (float)x1i}, dy = my - f32x2{(float)y0i, (float)y1i};
+  // texel (i, j) of the shifted image = pool texel (mirror(i - shx), mirror(j - shy)): for 0 <= shift <= size, -k -> k - 1
+  auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
+  const int nx0 = dx.x > 0 ? x0i + 1 : x0i, ny0 = dy.x > 0 ? y0i + 1 : y0i;
+  const int nx1 = dx.y > 0 ? x1i + 1 : x1i, ny1 = dy.y > 0 ? y1i + 1 : y1i;
+  const uint32_t ra0 = (uint32_t)sh(y0i, p.shy) * (uint32_t)pw, rb0 = (uint32_t)sh(ny0, p.shy) * (uint32_t)pw;
+  const uint32_t ra1 = (uint32_t)sh(y1i, p.shy) * (uint32_t)pw, rb1 = (uint32_t)sh(ny1, p.shy) * (uint32_t)pw;
+  const uint32_t xa0 = (uint32_t)sh(x0i, p.shx), xb0 = (uint32_t)sh(nx0, p.shx), xa1 = (uint32_t)sh(x1i, p.shx), xb1 = (uint32_t)sh(nx1, p.shx);
+  const uint32_t cc0 = img[ra0 + xa0], nc0 = img[ra0 + xb0], cn0 = img[rb0 + xa0], nn0 = img[rb0 + xb0];
+  uint32_t cc1 = 0, nc1 = 0, cn1 = 0, nn1 = 0;
+  if (second) { cc1 = img[ra1 + xa1]; nc1 = img[ra1 + xb1]; cn1 = img[rb1 + xa1]; nn1 = img[rb1 + xb1]; }
+  uint2 out = make_uint2(0, 0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int b = 8 * c;
+    const f32x2 Icc = {(float)((cc0 >> b) & 255u), (float)((cc1 >> b) & 255u)}, Inc = {(float)((nc0 >> b) & 255u), (float)((nc1 >> b) & 255u)};
+    const f32x2 Icn = {(float)((cn0 >> b) & 255u), (float)((cn1 >> b) & 255u)}, Inn = {(float)((nn0 >> b) & 255u), (float)((nn1 >> b) & 255u)};
+    // Icc + dx*(Inc - Icc + dy*(Icc + Inn - Icn - Inc)) + dy*(Icn - Icc)
+    const f32x2 t = ((Icc + Inn) - Icn) - Inc;
+    const f32x2 val = (Icc + dx * ((Inc - Icc) + dy * t)) + dy * (Icn - Icc);
+    out.x |= (uint32_t)(unsigned char)val.x << b;
+    out.y |= (uint32_t)(unsigned char)val.y << b;
+  }
+  return out;
+}
+// C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y; a thread takes texel PAIRS
 __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H,
                                                              int cap_cw, int cap_ch, uint32_t* __restrict__ C, uint32_t* __restrict__ err) {
   const int s = blockIdx.y;
@@ -2020,16 +2064,21 @@ __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __
     return;
   }
   const int rw_ = cx1 - cx0 + 1, rh_ = cy1 - cy0 + 1;
+  const int pairs = (rw_ + 1) / 2;  // texel pairs per row of the region
   uint32_t* Cs = C + (size_t)s * cap_cw * cap_ch;
-  const float inv_rw = 1.0f / (float)rw_;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < rw_ * rh_; k += gridDim.x * blockDim.x) {  // (the region's size is only known on the device)
-    int jj = (int)((float)k * inv_rw);  // k / rw_ (k < 2^22: the float quotient is off by one at most)
-    int ii = k - jj * rw_;
-    if (ii < 0) { --jj; ii += rw_; } else if (ii >= rw_) { ++jj; ii -= rw_; }
-    const int j = cy0 + jj, i = cx0 + ii;
-    const int rx = mirror_index(p.x0 + i, p.rw), ry = mirror_index(p.y0 + j, p.rh);
-    const float xc = __fsub_rn((float)rx, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-    Cs[(uint32_t)(j * p.cw + i)] = bgprep_rot_sample(p, xc, yc);
+  const float inv_pairs = 1.0f / (float)pairs;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < pairs * rh_; k += gridDim.x * blockDim.x) {  // (the region's size is only known on the device)
+    int jj = (int)((float)k * inv_pairs);  // k / pairs (k < 2^22: the float quotient is off by one at most)
+    int pi = k - jj * pairs;
+    if (pi < 0) { --jj; pi += pairs; } else if (pi >= pairs) { ++jj; pi -= pairs; }
+    const int j = cy0 + jj, i = cx0 + 2 * pi;
+    const bool second = i + 1 <= cx1;
+    const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+    const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+    const uint2 v = bgprep_rot_sample2(p, xc0, xc1, yc, second);
+    const uint32_t o = (uint32_t)(j * p.cw + i);
+    Cs[o] = v.x;
+    if (second) Cs[o + 1] = v.y;
   }
 }
 // a / d correctly rounded for operands that need none of the IEEE division's range handling (here 0 <= a < 2^31,

@@ -266,6 +266,32 @@ def main():
         dist.all_gather(shards, mine)
     shards = [[int(v) for v in t.tolist()] for t in shards]
 
+    compose_ms = gen.kernel_ms("compose")
+    parts = alone = cpu_base = None
+    if rank == 0:
+        # second short pass with all three kernels timed (not part of `value`)
+        gen.set_profiling(2)
+        for i in range(min(args.steps, 48)):
+            step(i)
+        gen.synchronize(stream)
+        parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        # third short pass, one batch at a time (device idle between the steps): the kernels' durations with nothing
+        # else in flight - what one launch of the compose kernel takes when it has the GPU to itself
+        gen.set_profiling(2)
+        for i in range(min(args.steps, 32)):
+            step(i)
+            gen.synchronize(stream)
+        alone = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        gen.set_profiling(0)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_base = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool)
+    ctx_info, n_chains = gen.info(), gen.num_chains()
+    # The headline context is closed before the reference-equivalent one is made: two contexts would own ten streams on the
+    # process's eight hardware queues, and chains that share a queue run one after the other.
+    gen.synchronize(stream)
+    gen.close()
+    del gen
+
     # the reference-equivalent pass: the same workload with Texture::getRandomizedCrop on every background
     ref_eq = None
     if not args.no_reference_equivalent and not args.background_prep and counter:
@@ -300,24 +326,10 @@ def main():
                           "textures are extra traffic)"}
         if world == 1 and not args.no_cpu_baseline:
             ref_eq["cpu_baseline"] = cpu_baseline(ofdg, gen2, cfg, budget_s=12.0, host_pool=args.cpu_pool, background_prep=1)
+        gen2.close()
         del gen2
 
-    compose_ms = gen.kernel_ms("compose")
     if rank == 0:
-        # second short pass with all three kernels timed (not part of `value`)
-        gen.set_profiling(2)
-        for i in range(min(args.steps, 48)):
-            step(i)
-        gen.synchronize(stream)
-        parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
-        # third short pass, one batch at a time (device idle between the steps): the kernels' durations with nothing
-        # else in flight - what one launch of the compose kernel takes when it has the GPU to itself
-        gen.set_profiling(2)
-        for i in range(min(args.steps, 32)):
-            step(i)
-            gen.synchronize(stream)
-        alone = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
-        gen.set_profiling(0)
         alg_bytes_per_sample = 38 * W * H  # 32 B/px written (8 fp32 planes) + 6 B/px background read
         samples = args.steps * BATCH * world
         value = samples / dt
@@ -339,8 +351,8 @@ def main():
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
             "config": {"workload": cfg["name"], "baseline_config": args.config, "batch_per_gpu": BATCH,
                        "background_prep": bool(args.background_prep), "startup": startup, "rccl_ranks": rccl_ranks,
-                       "shards": {"first_index_of_steps_0_and_1_by_rank": shards}, "context": gen.info(), "output_buffer_sets": NBUF,
-                       "chains": gen.num_chains(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "shards": {"first_index_of_steps_0_and_1_by_rank": shards}, "context": ctx_info, "output_buffer_sets": NBUF,
+                       "chains": n_chains, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
                                    if counter else "ref (host mt19937 streams) inside the timed region" if cfg["sampler"] == "ref" else
                                    "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},
@@ -367,8 +379,8 @@ def main():
         out["reference_equivalent"] = ref_eq
         if host_sampler_rate is not None:
             out["host_ref_sampler_samples_per_s"] = host_sampler_rate
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -2014,31 +2014,40 @@ __device__ __forceinline__ bool bgprep_region(const DevBgPrep& p, const DevResiz
 // - when no lane of the wave leaves the image (no mirroring, no clamping: the usual case, the rotation is a few degrees) -
 // without the wrap logic.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint2 bgprep_rot_sample2(const DevBgPrep& p, float xc0, float xc1, float yc, bool second) {
-  OFDG_GLOBAL const uint32_t* img = (OFDG_GLOBAL const uint32_t*)p.image_addr;
-  const int pw = p.pw, ph = p.ph;
+struct RotPair { f32x2 mx, my; };
+// mx = (w2 + xc * ca) + yc * sa;  my = (h2 - xc * sa) + yc * ca   (element-wise: exactly the scalar sequence)
+__device__ __forceinline__ RotPair bgprep_rot_coords(const DevBgPrep& p, float xc0, float xc1, float yc) {
   const f32x2 xc = {xc0, xc1};
-  // mx = (w2 + xc * ca) + yc * sa;  my = (h2 - xc * sa) + yc * ca   (element-wise: exactly the scalar sequence)
-  const f32x2 mx = (f32x2{p.w2, p.w2} + xc * f32x2{p.ca, p.ca}) + f32x2{__fmul_rn(yc, p.sa), __fmul_rn(yc, p.sa)};
-  const f32x2 my = (f32x2{p.h2, p.h2} - xc * f32x2{p.sa, p.sa}) + f32x2{__fmul_rn(yc, p.ca), __fmul_rn(yc, p.ca)};
-  // inside [0, pw - 1) x [0, ph - 1): mod, mirror and the Neumann clamp are identities, nx = x + 1 exists
-  const bool in0 = mx.x >= 0.f && mx.x < (float)(pw - 1) && my.x >= 0.f && my.x < (float)(ph - 1);
-  const bool in1 = !second || (mx.y >= 0.f && mx.y < (float)(pw - 1) && my.y >= 0.f && my.y < (float)(ph - 1));
-  const bool shift_plain = p.shx >= 0 && p.shx <= pw && p.shy >= 0 && p.shy <= ph;  // (uniform)
-  if (__ballot(!(in0 && in1)) != 0ull || !shift_plain)
-    return make_uint2(bgprep_rot_sample(p, xc0, yc), second ? bgprep_rot_sample(p, xc1, yc) : 0u);
+  RotPair r;
+  r.mx = (f32x2{p.w2, p.w2} + xc * f32x2{p.ca, p.ca}) + f32x2{__fmul_rn(yc, p.sa), __fmul_rn(yc, p.sa)};
+  r.my = (f32x2{p.h2, p.h2} - xc * f32x2{p.sa, p.sa}) + f32x2{__fmul_rn(yc, p.ca), __fmul_rn(yc, p.ca)};
+  return r;
+}
+__device__ __forceinline__ bool bgprep_shift_plain(const DevBgPrep& p) { return p.shx >= 0 && p.shx <= p.pw && p.shy >= 0 && p.shy <= p.ph; }
+// Both texels lie inside [0, pw - 1) x [0, ph - 1) of the rotated image's source coordinates (mod, mirror and the Neumann
+// clamp are identities, x + 1 and y + 1 exist) and the shift is plain (0 <= shift <= size).
+__device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const RotPair& r, bool second) {
+  const f32x2 mx = r.mx, my = r.my;
   const int x0i = (int)mx.x, y0i = (int)my.x, x1i = (int)mx.y, y1i = (int)my.y;
   const f32x2 dx = mx - f32x2{(float)x0i, (float)x1i}, dy = my - f32x2{(float)y0i, (float)y1i};
-  // texel (i, j) of the shifted image = pool texel (mirror(i - shx), mirror(j - shy)): for 0 <= shift <= size, -k -> k - 1
+  // The neighbours are ALWAYS x + 1 and y + 1 here: where dx (dy) is 0 the scalar form reads the texel itself instead, but
+  // the neighbour's weight is then an exact zero and the value the same.  Texel (i, j) of the shifted image = pool texel
+  // (mirror(i - shx), mirror(j - shy)), for 0 <= shift <= size -k -> k - 1: x and x + 1 are neighbours in the pool too
+  // (ascending, descending left of the mirror line, or twice texel 0 across it), so ONE 8-byte load per row fetches both.
+  const char* imgc = (const char*)p.image_addr;
   auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
-  const int nx0 = dx.x > 0 ? x0i + 1 : x0i, ny0 = dy.x > 0 ? y0i + 1 : y0i;
-  const int nx1 = dx.y > 0 ? x1i + 1 : x1i, ny1 = dy.y > 0 ? y1i + 1 : y1i;
-  const uint32_t ra0 = (uint32_t)sh(y0i, p.shy) * (uint32_t)pw, rb0 = (uint32_t)sh(ny0, p.shy) * (uint32_t)pw;
-  const uint32_t ra1 = (uint32_t)sh(y1i, p.shy) * (uint32_t)pw, rb1 = (uint32_t)sh(ny1, p.shy) * (uint32_t)pw;
-  const uint32_t xa0 = (uint32_t)sh(x0i, p.shx), xb0 = (uint32_t)sh(nx0, p.shx), xa1 = (uint32_t)sh(x1i, p.shx), xb1 = (uint32_t)sh(nx1, p.shx);
-  const uint32_t cc0 = img[ra0 + xa0], nc0 = img[ra0 + xb0], cn0 = img[rb0 + xa0], nn0 = img[rb0 + xb0];
-  uint32_t cc1 = 0, nc1 = 0, cn1 = 0, nn1 = 0;
-  if (second) { cc1 = img[ra1 + xa1]; nc1 = img[ra1 + xb1]; cn1 = img[rb1 + xa1]; nn1 = img[rb1 + xb1]; }
+  auto row_pair = [&](int xi, uint32_t ra, uint32_t rb, uint32_t* cc, uint32_t* nc, uint32_t* cn, uint32_t* nn) {
+    const int j = xi - p.shx;
+    const uint32_t base = (uint32_t)(j >= 0 ? j : max(-j - 2, 0));
+    const uint2 r0 = gload2(imgc, (ra + base) * 4u), r1 = gload2(imgc, (rb + base) * 4u);
+    const bool rev = j < 0, swap = j < -1;
+    *cc = swap ? r0.y : r0.x; *nc = rev ? r0.x : r0.y;
+    *cn = swap ? r1.y : r1.x; *nn = rev ? r1.x : r1.y;
+  };
+  const uint32_t upw = (uint32_t)p.pw;
+  uint32_t cc0, nc0, cn0, nn0, cc1 = 0, nc1 = 0, cn1 = 0, nn1 = 0;
+  row_pair(x0i, __umul24((uint32_t)sh(y0i, p.shy), upw), __umul24((uint32_t)sh(y0i + 1, p.shy), upw), &cc0, &nc0, &cn0, &nn0);
+  if (second) row_pair(x1i, __umul24((uint32_t)sh(y1i, p.shy), upw), __umul24((uint32_t)sh(y1i + 1, p.shy), upw), &cc1, &nc1, &cn1, &nn1);
   uint2 out = make_uint2(0, 0);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -2052,6 +2061,15 @@ __device__ __forceinline__ uint2 bgprep_rot_sample2(const DevBgPrep& p, float xc
     out.y |= (uint32_t)(unsigned char)val.y << b;
   }
   return out;
+}
+__device__ __forceinline__ uint2 bgprep_rot_sample2(const DevBgPrep& p, float xc0, float xc1, float yc, bool second) {
+  const int pw = p.pw, ph = p.ph;
+  const RotPair r = bgprep_rot_coords(p, xc0, xc1, yc);
+  const bool in0 = r.mx.x >= 0.f && r.mx.x < (float)(pw - 1) && r.my.x >= 0.f && r.my.x < (float)(ph - 1);
+  const bool in1 = !second || (r.mx.y >= 0.f && r.mx.y < (float)(pw - 1) && r.my.y >= 0.f && r.my.y < (float)(ph - 1));
+  if (__ballot(!(in0 && in1)) != 0ull || !bgprep_shift_plain(p))
+    return make_uint2(bgprep_rot_sample(p, xc0, yc), second ? bgprep_rot_sample(p, xc1, yc) : 0u);
+  return bgprep_rot_inside2(p, r, second);
 }
 // C(i, j) = R(mirror(x0 + i), mirror(y0 + j)), R = rotate(shift(T)); sample blockIdx.y; a thread takes texel PAIRS
 __global__ __launch_bounds__(256) void bgprep_rotcrop_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H,
@@ -2175,6 +2193,105 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
     } else {  // (a crop beyond 4/3 of the texture is refused before it gets here; kept for safety)
       for (int y = y0; y <= y1; ++y) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel(p.ch, TH, y, at_y, alpha_y, c_row);
     }
+  }
+}
+
+// ---- the same chain in ONE launch (pool images at least 2W x 2H: a crop is at most 4/3 of the texture) ------------------
+// A workgroup renders kFuseW x kFuseH tiles of B.  Per tile: the texels of C the tile needs (cimg_resize_range of its
+// columns and rows: at most 4/3 of the tile + 2 each way) are sampled into LDS; M = X-resize of C overwrites C's rows in
+// place (a row belongs to ONE wave: its lanes read the row's texels before any of them writes); B = Y-resize of M goes to
+// memory.  C and M never leave the CU, the per-column table entries are loaded once per tile instead of once per texel,
+// and the two launches (with the round trip of C through HBM between them) become one.  The tiles of all samples are
+// numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
+constexpr int kFuseW = 64, kFuseH = 32;
+constexpr int kFuseCW = 90, kFuseCH = 48;  // 64 * 4/3 + 2 columns (even: texel pairs), 32 * 4/3 + 2 rows, and a margin for the +2 of the crop size
+// (six waves per SIMD: 79 VGPRs; at the five the compiler picks by itself the kernel is 2 % slower in the pipeline, at eight it spills)
+__global__ __launch_bounds__(256, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
+                                                           int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
+  __shared__ uint32_t s_c[kFuseCH][kFuseCW];
+  const int TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int s = 0, first = 0;  // tiles of the samples before s
+  for (int t = blockIdx.x;; t += gridDim.x) {
+    int tcols = 0, ntiles = 0;
+    for (; s < n_samples; ++s) {  // the sample that holds tile t (t only grows: every workgroup walks the samples once)
+      const DevBgPrep& q = prep[s];
+      const bool fits = q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch;
+      if (!fits && blockIdx.x == 0 && tid == 0) atomicOr(err, kErrBgPrepCapacity);
+      tcols = fits ? (q.rx1 - q.rx0 + kFuseW) / kFuseW : 0;
+      ntiles = fits ? tcols * ((q.ry1 - q.ry0 + kFuseH) / kFuseH) : 0;
+      if (t < first + ntiles) break;
+      first += ntiles;
+    }
+    if (s >= n_samples) return;
+    const DevBgPrep p = prep[s];
+    const int ti = t - first, ty = ti / tcols, tx = ti - ty * tcols;
+    const int bx0 = p.rx0 + tx * kFuseW, bx1 = min(bx0 + kFuseW - 1, p.rx1);
+    const int by0 = p.ry0 + ty * kFuseH, by1 = min(by0 + kFuseH - 1, p.ry1);
+    int cx0, cx1, cy0, cy1;
+    cimg_resize_range(p.cw, TW, bx0, bx1, T.at_x, &cx0, &cx1);
+    cimg_resize_range(p.ch, TH, by0, by1, T.at_y, &cy0, &cy1);
+    const int ncw = cx1 - cx0 + 1, nch = cy1 - cy0 + 1;
+    if (ncw > kFuseCW || nch > kFuseCH) {  // (a crop beyond 4/3 of the texture: the host launches the two-kernel form for such pools)
+      if (tid == 0) atomicOr(err, kErrBgPrepCapacity);
+      continue;
+    }
+    // C(i, j), texel pairs
+    const int pairs = (ncw + 1) / 2;
+    const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48 (pairs <= 45; both factors below 2^24)
+    // The usual tile: its crop coordinates need no mirroring and its four corners - so, the map being affine, all its texels
+    // (a margin of one texel covers the rounding of the per-texel evaluation) - lie inside the source image: no per-texel tests.
+    bool inside = bgprep_shift_plain(p) && p.x0 + cx0 >= 0 && p.x0 + cx1 + 1 < p.rw && p.y0 + cy0 >= 0 && p.y0 + cy1 < p.rh;
+    if (inside) {
+      const float xa = __fsub_rn((float)(p.x0 + cx0), p.rw2), xb = __fsub_rn((float)(p.x0 + cx1 + 1), p.rw2);
+      const float ya = __fsub_rn((float)(p.y0 + cy0), p.rh2), yb = __fsub_rn((float)(p.y0 + cy1), p.rh2);
+      const RotPair ra = bgprep_rot_coords(p, xa, xb, ya), rb = bgprep_rot_coords(p, xa, xb, yb);
+      const float lo_x = fminf(fminf(ra.mx.x, ra.mx.y), fminf(rb.mx.x, rb.mx.y)), hi_x = fmaxf(fmaxf(ra.mx.x, ra.mx.y), fmaxf(rb.mx.x, rb.mx.y));
+      const float lo_y = fminf(fminf(ra.my.x, ra.my.y), fminf(rb.my.x, rb.my.y)), hi_y = fmaxf(fmaxf(ra.my.x, ra.my.y), fmaxf(rb.my.x, rb.my.y));
+      inside = lo_x >= 1.f && hi_x < (float)(p.pw - 2) && lo_y >= 1.f && hi_y < (float)(p.ph - 2);
+    }
+    if (inside) {
+      for (int k = tid; k < pairs * nch; k += 256) {
+        const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+        const int pi = k - jj * pairs;
+        const int xi = p.x0 + cx0 + 2 * pi;
+        const RotPair r = bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + jj), p.rh2));
+        *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_inside2(p, r, true);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
+      }
+    } else
+    for (int k = tid; k < pairs * nch; k += 256) {
+      const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+      const int pi = k - jj * pairs;
+      const int i = cx0 + 2 * pi, j = cy0 + jj;
+      const bool second = i + 1 <= cx1;
+      const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+      const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+      const uint2 v = bgprep_rot_sample2(p, xc0, xc1, yc, second);
+      *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = v;
+    }
+    __syncthreads();
+    // M(x, j) over C(., j), in place: wave w takes rows w, w + 4, ...; lane = column of the tile
+    const int x = bx0 + lane;
+    const uint16_t* at_x = T.at_x + (size_t)p.cw * TW;
+    const double* alpha_x = T.alpha_x + (size_t)p.cw * TW;
+    for (int jj = wave; jj < nch; jj += 4) {
+      uint32_t m = 0;
+      if (x <= bx1) m = cimg_resize_texel(p.cw, TW, x, at_x, alpha_x, [&](int i) { return s_c[jj][i - cx0]; });
+      __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
+      if (x <= bx1) s_c[jj][lane] = m;
+    }
+    __syncthreads();
+    // B(x, y) over M(x, .): wave w takes rows 8 w .. 8 w + 7 of the tile
+    const uint16_t* at_y = T.at_y + (size_t)p.ch * TH;
+    const double* alpha_y = T.alpha_y + (size_t)p.ch * TH;
+    uint32_t* Bs = B + (size_t)s * TW * TH;
+    if (x <= bx1) {
+      for (int r = 0; r < kFuseH / 4; ++r) {
+        const int y = by0 + wave * (kFuseH / 4) + r;
+        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel(p.ch, TH, y, at_y, alpha_y, [&](int j) { return s_c[j - cy0][lane]; });
+      }
+    }
+    __syncthreads();  // (the next tile overwrites the rows)
   }
 }
 

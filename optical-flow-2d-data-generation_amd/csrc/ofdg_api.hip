@@ -798,6 +798,16 @@ static int ensure_tex_table(ofdg_ctx* c) {
   HIP_OK(c, hipMemcpy(c->d_tex_table, c->tex_table.data(), c->tex_table.size() * sizeof(DevTexEntry), hipMemcpyHostToDevice));
   return OFDG_OK;
 }
+// every pool image at least 2W x 2H: a crop is at most 4/3 of the texture (beyond that it is refused), which is what the
+// tiles of bgprep_fused_kernel hold; smaller images are resized by any factor (DG:102-106): the two-kernel form
+static bool bgprep_fusable(const ofdg_ctx* c) {
+  const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
+  if (c->pool_mixed) {
+    for (const auto& wh : c->mixed_sizes) if (wh.first < TW || wh.second < TH) return false;
+    return true;
+  }
+  return c->pool_w >= TW && c->pool_h >= TH;
+}
 static void bgprep_caps(ofdg_ctx* c, int* cap_cw, int* cap_ch) {
   if (c->bg_cap_n == c->pool_n && c->bg_cap_cw > 0) { *cap_cw = c->bg_cap_cw; *cap_ch = c->bg_cap_ch; return; }  // (per pool, not per step)
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
@@ -1055,15 +1065,15 @@ static int ensure_bgprep_tables(ofdg_ctx* c) {
 // background_prep: (upload the records of n samples and) render their 2W x 2H background
 // textures into the slot's buffer on stream `s` (bgprep_kernel)
 static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s) {
-  const int W = c->prm.width, H = c->prm.height, TW = 2 * W, TH = 2 * H;
+  const int W = c->prm.width, H = c->prm.height;
   HIP_OK(c, sl.d_bgprep.reserve(n));
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
   int cap_cw, cap_ch;
   bgprep_caps(c, &cap_cw, &cap_ch);
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
+  constexpr int kBgPrepFusedBlocks = 512;  // two workgroups per CU walk the batch's tiles (320 .. 640: the same step rate; more crowd compose out)
   if (staged) {
-    HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;
   }
@@ -1077,6 +1087,12 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
     return OFDG_OK;
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
+  if (bgprep_fusable(c)) {
+    hipLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, c->d_err);
+    HIP_OK(c, hipGetLastError());
+    return OFDG_OK;
+  }
+  HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
   hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
                      c->d_err);
   hipLaunchKernelGGL(bgprep_resize_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,

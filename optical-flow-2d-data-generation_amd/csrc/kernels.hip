@@ -1024,8 +1024,7 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops, const unsigned long long* __restrict__ deform_mask,
-                                             int bid, int tid) {
+                                             const DevCropRef* __restrict__ crops, int bid, int tid) {
   const int tiles = dm.tiles_x * dm.tiles_y;
   const int s = bid / tiles;
   if (s >= dm.n_samples) return;
@@ -1049,10 +1048,6 @@ __device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSamp
     mask0 = mm.x; mask1 = mm.y;
   }
   unsigned long long omask = mask0 | mask1;
-  if constexpr (kDeform) {
-    // the strips nothing deformed touches are the rigid kernel's (compose_rigid_part_kernel, launched beside this one)
-    if (deform_mask && objs[0].deform <= 0 && (deform_mask[s] & omask) == 0ull) return;
-  }
 
   const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
   const size_t slot_bytes = (size_t)W * H;
@@ -1333,8 +1328,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
                                              float* __restrict__ img0, float* __restrict__ img1,
                                              float* __restrict__ flow,
                                              const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count,
-                                             const unsigned long long* __restrict__ deform_mask) {
+                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
   // raster_kernel has consumed the work list: reset the counter for this slot's next launch
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
   // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch).  Every XCD takes
@@ -1349,7 +1343,7 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   }
   // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
   // of four sibling waves retires
-  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, deform_mask, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
+  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
 }
 
 // Mode 9: the same kernel with the deformation paths compiled in.
@@ -1357,18 +1351,16 @@ __global__ __launch_bounds__(64) void compose_deform_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count,
-    const unsigned long long* __restrict__ deform_mask) {
-  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count, deform_mask);
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
 }
 // Mode 9, W a power of two.
 __global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count,
-    const unsigned long long* __restrict__ deform_mask) {
-  compose_body<true, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count, deform_mask);
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_body<true, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
 }
 
 struct Taps4 {
@@ -1466,14 +1458,13 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 // --------------------------------------------------------------------------
 constexpr int kPre = 2;  // objects of a block whose header / coverage / record are fetched ahead of their visit
 
-template <bool kPow2, bool kPart = false>
+template <bool kPow2>
 __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
                                               const DevObject* __restrict__ objects, const uint8_t* __restrict__ cov,
                                               int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
                                               const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
                                               float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-                                              const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count,
-                                              const unsigned long long* __restrict__ deform_mask = nullptr) {
+                                              const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
   static_assert(kPx == 4, "mask bytes are packed four to a word");
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // raster_kernel has consumed the work list
   // XCD-aware strip mapping (see compose_body)
@@ -1513,11 +1504,6 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
                       "+s"(smp.bg_motion.tx), "+s"(smp.bg_motion.ty));
   }
   unsigned long long omask = mask0 | mask1;
-  if constexpr (kPart) {
-    // mode 9: a strip that a deformed object or a deformed background touches is compose_deform_kernel's (launched behind
-    // this one over the same strips, with the opposite test)
-    if (samples[s].bg_deform > 0 || (deform_mask[s] & omask) != 0ull) return;
-  }
   const DevObject* objs = objects + smp.first_object;
   const uint32_t pix = (uint32_t)(y * W + x0);
   const size_t slot_bytes = (size_t)W * H;
@@ -1785,26 +1771,6 @@ __global__ __launch_bounds__(64) void compose_rigid_pow2_kernel(
     float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
   compose_rigid<true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
                       flow, frames, item_count);
-}
-
-// Mode 9: the rigid kernel over the strips nothing deformed touches (see compose_rigid's kPart test).
-__global__ __launch_bounds__(64) void compose_rigid_part_kernel(
-    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
-    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
-    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count,
-    const unsigned long long* __restrict__ deform_mask) {
-  compose_rigid<false, true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0,
-                             img1, flow, frames, item_count, deform_mask);
-}
-__global__ __launch_bounds__(64) void compose_rigid_part_pow2_kernel(
-    const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask, const DevObject* __restrict__ objects,
-    const uint8_t* __restrict__ cov, int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
-    const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1,
-    float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count,
-    const unsigned long long* __restrict__ deform_mask) {
-  compose_rigid<true, true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0,
-                            img1, flow, frames, item_count, deform_mask);
 }
 
 // --------------------------------------------------------------------------

@@ -78,7 +78,6 @@ struct ofdg_ctx {
     DevBuf<int2> d_verts;
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
-    DevBuf<unsigned long long> d_deform;  // mode 9: per sample, the deformed foreground objects (bits of the block masks)
     DevBuf<int4> d_items;
     DevBuf<DevBgPrep> d_bgprep;   // background_prep: one record ...
     DevBuf<uint32_t> d_bgtex;     // ... and one prepared 2W x 2H BGRX texture per sample
@@ -339,7 +338,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   for (uint32_t* im : c->mixed_images) if (im) (void)hipFree(im);
   if (c->d_tex_table) (void)hipFree(c->d_tex_table);
   auto drop_slot = [](ofdg_ctx::Slot& sl) {
-    sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release(); sl.d_deform.release();
+    sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
     sl.d_bgC.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
@@ -842,7 +841,7 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
                   c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin,
                   (unsigned long long)(uintptr_t)c->pool, c->d_tex_table};
   hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
-                     sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p, c->prm.mode == 9 ? sl.d_deform.p : nullptr);
+                     sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
   if (prep) {
     int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s);
@@ -989,28 +988,14 @@ static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float
   hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
   // (profiled launches: start and stop are the timestamps of the compose kernel's own dispatch packet)
   hipEvent_t k_start = ev ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
-  if (c->prm.mode == 9) {
-    // Two launches over the same strips: the rigid kernel (86 VGPRs, five waves per SIMD) renders the strips no deformed
-    // object and no deformed background touches and leaves the others at once; the deformation kernel (158 VGPRs, three
-    // waves) does the reverse.  Which is which: the sample's deformed-object word against the block's masks.
-    const unsigned long long* dmask = sl.d_deform.p;
-    if (!dmask) { c->err = "internal: mode 9 without the samples' deformation words"; return OFDG_EINVAL; }
-    if ((W & (W - 1)) == 0) {
-      hipExtLaunchKernelGGL(compose_rigid_part_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, nullptr, 0, sl.d_samples.p, box_cur,
-                            sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                            d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count, dmask);
-      hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, nullptr, k_stop, 0, dm, sl.d_samples.p,
-                            sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
-                            sl.d_item_count, dmask);
-    } else {
-      hipExtLaunchKernelGGL(compose_rigid_part_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, nullptr, 0, sl.d_samples.p, box_cur,
-                            sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
-                            d_img0, d_img1, d_flow, sl.d_frames.p, sl.d_item_count, dmask);
-      hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, nullptr, k_stop, 0, dm, sl.d_samples.p,
-                            sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
-                            sl.d_item_count, dmask);
-    }
-  }
+  if (c->prm.mode == 9 && (W & (W - 1)) == 0)
+    hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_item_count);
+  else if (c->prm.mode == 9)
+    hipExtLaunchKernelGGL(compose_deform_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
+                          sl.d_objects.p, box_cur, cov, fgpool, bgpool, d_img0, d_img1, d_flow, sl.d_frames.p, croptab,
+                          sl.d_item_count);
   else if ((W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_rigid_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, sl.d_samples.p, box_cur,
                           sl.d_objects.p, cov, compose_grid, dm.tiles_x, dm.tiles_y, W, H, dm.use_aa, dm.bg_pitch, dm.fg_pitch, fgpool, bgpool,
@@ -1155,9 +1140,8 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n_tasks));
   const size_t b_shapes = n_shapes * sizeof(DevShape), b_obj = n_obj * sizeof(DevObject),
-               b_smp = (size_t)n_tasks * sizeof(DevSample), b_def = B.deform.size() * sizeof(uint64_t);
-  if (b_def) HIP_OK(c, sl.d_deform.reserve(B.deform.size()));
-  const size_t need = b_shapes + b_obj + b_smp + b_def + 64;
+               b_smp = (size_t)n_tasks * sizeof(DevSample);
+  const size_t need = b_shapes + b_obj + b_smp + 64;
   if (need > stage.bytes) {
     if (stage.h) HIP_OK(c, hipHostFree(stage.h));
     stage.h = nullptr;
@@ -1171,10 +1155,6 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   if (b_shapes) HIP_OK(c, hipMemcpyAsync(sl.d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipMemcpyAsync(sl.d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipMemcpyAsync(sl.d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
-  if (b_def) {
-    std::memcpy(hs + b_shapes + b_obj + b_smp, B.deform.data(), b_def);
-    HIP_OK(c, hipMemcpyAsync(sl.d_deform.p, hs + b_shapes + b_obj + b_smp, b_def, hipMemcpyHostToDevice, st));
-  }
   if (!B.crops.empty()) {  // mode 9: this batch's crop table (+ upscaled background copies)
     const int W = c->prm.width, H = c->prm.height;
     const size_t crop_floats = (size_t)4 * (W + 1) * (H + 1), bg_floats = (size_t)4 * 2 * W * 2 * H;
@@ -1277,7 +1257,6 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
   HIP_OK(c, sl.d_verts.reserve(shapes_cap * 2 * kMaxVerts));
   HIP_OK(c, sl.d_objects.reserve(n_obj));
   HIP_OK(c, sl.d_samples.reserve(n));
-  if (c->prm.mode == 9) HIP_OK(c, sl.d_deform.reserve(n));
   { int rcw = reserve_workspaces(c, shapes_cap); if (rcw != OFDG_OK) return rcw; }
   HIP_OK(c, sl.d_items.reserve(shapes_cap * 2 * (size_t)((H + kBandRows - 1) / kBandRows) * ((W + kChunkW - 1) / kChunkW) + 1));
   { int rcm = reserve_blockmask(c, sl, n); if (rcm != OFDG_OK) return rcm; }

@@ -111,7 +111,6 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
   out->samples.clear();
   out->crops.clear();
   out->bgprep.clear();
-  out->deform.clear();
   const bool mode9 = (cfg.mode == 9);
   auto serve = [&](bool background) -> int {  // returns deform = table index + 1
     out->crops.push_back(CropUse{crops->get(), background ? 1 : 0});
@@ -184,7 +183,6 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       out->objects.push_back(o);
     }
     // foreground objects; std::map order == ascending obj_id (DataGenerator.cpp:1216-1223)
-    uint64_t deform_bits = 0;  // mode 9: the sample's deformed foreground objects (the mode-9 compose launches split the strips by it)
     std::vector<int> order(task.n_objects);
     for (int i = 0; i < task.n_objects; ++i) order[i] = task.first_object + i;
     for (size_t i = 1; i < order.size(); ++i)  // insertion sort by id (already sorted when sampled)
@@ -229,14 +227,12 @@ int realize_batch(const RealizeConfig& cfg, const ofdg_task* tasks, int n_tasks,
       {
         const int local = (int)out->objects.size() - smp.first_object - 1;  // bit of the block masks
         smp.shape_of[local] = (uint16_t)((o.first_shape - smp.first_shape) | (o.kind == 2 ? kShapeComposite : 0));
-        if (o.deform > 0) deform_bits |= 1ull << local;
       }
       out->objects.push_back(o);
     }
     smp.n_objects = (int32_t)out->objects.size() - smp.first_object;
     smp.n_shapes = (int32_t)out->shapes.size() - smp.first_shape;
     out->samples.push_back(smp);
-    if (mode9) out->deform.push_back(deform_bits);
   }
   return OFDG_OK;
 }

@@ -56,7 +56,6 @@ struct RealizedBatch {
   std::vector<DevSample> samples;
   std::vector<CropUse> crops;  // DevObject/DevShape.deform - 1 indexes this table
   std::vector<DevBgPrep> bgprep;  // per sample, if RealizeConfig.background_prep
-  std::vector<uint64_t> deform;   // per sample, mode 9: bit k = foreground object k (bit of the block masks) is deformed
 };
 
 // CropGenerator::get_crop (WarpFields.cpp:516-538): crops are served in order, each

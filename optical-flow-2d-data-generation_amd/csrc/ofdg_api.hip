@@ -1717,7 +1717,7 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
   c->profiling = mode;
   c->ev_count = 0; c->ev_alloc = 0;
   c->launch_count = 0;
-  c->ev_stride = (mode == 1) ? 4 : 1;  // mode 1 samples every 4th launch: keeps the event cost out of throughput runs
+  c->ev_stride = (mode == 1) ? 8 : 1;  // mode 1 samples every 8th launch: a profiled compose waits ~6 us for its start marker (every 4th: -1.2 % on a long run, -3.5 % on a 20-step one)
   if (mode && c->ev.empty()) {
     c->ev_sets = 256;
     c->ev.resize((size_t)c->ev_sets * 6);

@@ -174,6 +174,7 @@ struct ofdg_ctx {
   DevBuf<double> d_bg_alpha_x, d_bg_alpha_y;
   int bg_tab_w = 0, bg_tab_h = 0;
   int bg_cap_cw = 0, bg_cap_ch = 0, bg_cap_n = -1;  // bgprep_caps of the current pool (reset when the pool changes)
+  bool bg_fusable = false;
   uint32_t* h_err = nullptr;        // pinned copy for ofdg_poll_errors, on its own stream
   hipStream_t err_stream = nullptr;
   // profiling: ring of event sets, 6 events per launch: start/stop of geom, raster and compose,
@@ -798,27 +799,20 @@ static int ensure_tex_table(ofdg_ctx* c) {
   HIP_OK(c, hipMemcpy(c->d_tex_table, c->tex_table.data(), c->tex_table.size() * sizeof(DevTexEntry), hipMemcpyHostToDevice));
   return OFDG_OK;
 }
-// every pool image at least 2W x 2H: a crop is at most 4/3 of the texture (beyond that it is refused), which is what the
-// tiles of bgprep_fused_kernel hold; smaller images are resized by any factor (DG:102-106): the two-kernel form
-static bool bgprep_fusable(const ofdg_ctx* c) {
-  const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
-  if (c->pool_mixed) {
-    for (const auto& wh : c->mixed_sizes) if (wh.first < TW || wh.second < TH) return false;
-    return true;
-  }
-  return c->pool_w >= TW && c->pool_h >= TH;
-}
-static void bgprep_caps(ofdg_ctx* c, int* cap_cw, int* cap_ch) {
-  if (c->bg_cap_n == c->pool_n && c->bg_cap_cw > 0) { *cap_cw = c->bg_cap_cw; *cap_ch = c->bg_cap_ch; return; }  // (per pool, not per step)
+// `fusable`: every pool image is at least 2W x 2H, so a crop is at most 4/3 of the texture (beyond that it is refused), which
+// is what the tiles of bgprep_fused_kernel hold; smaller images are resized by any factor (DG:102-106): the two-kernel form
+static void bgprep_caps(ofdg_ctx* c, int* cap_cw, int* cap_ch, bool* fusable) {
+  if (c->bg_cap_n == c->pool_n && c->bg_cap_cw > 0) { *cap_cw = c->bg_cap_cw; *cap_ch = c->bg_cap_ch; *fusable = c->bg_fusable; return; }  // (per pool, not per step)
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
   // crops of the rotated image up to zoom 0.75 (the sampler draws 0.8 .. 1.2) ...
   int cw = (int)((float)TW / 0.75f) + 2, ch = (int)((float)TH / 0.75f) + 2;
   // ... or the whole rotated image when a pool image is smaller than 2W x 2H (DG:102-106; rotation by up to +-3.2 "degrees")
-  auto small = [&](int w, int h) { if (w < TW || h < TH) { cw = std::max(cw, w + h / 8 + 4); ch = std::max(ch, h + w / 8 + 4); } };
+  bool all_large = true;
+  auto small = [&](int w, int h) { if (w < TW || h < TH) { all_large = false; cw = std::max(cw, w + h / 8 + 4); ch = std::max(ch, h + w / 8 + 4); } };
   if (c->pool_mixed) for (const auto& wh : c->mixed_sizes) small(wh.first, wh.second);
   else small(c->pool_w, c->pool_h);
-  c->bg_cap_cw = cw; c->bg_cap_ch = ch; c->bg_cap_n = c->pool_n;
-  *cap_cw = cw; *cap_ch = ch;
+  c->bg_cap_cw = cw; c->bg_cap_ch = ch; c->bg_cap_n = c->pool_n; c->bg_fusable = all_large;
+  *cap_cw = cw; *cap_ch = ch; *fusable = all_large;
 }
 
 // per-chain coverage workspaces of a batch of n_shapes outlines.  Growing them waits for the device: every chain may be
@@ -1069,7 +1063,8 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   HIP_OK(c, sl.d_bgprep.reserve(n));
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
   int cap_cw, cap_ch;
-  bgprep_caps(c, &cap_cw, &cap_ch);
+  bool fusable;
+  bgprep_caps(c, &cap_cw, &cap_ch, &fusable);
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
   constexpr int kBgPrepFusedBlocks = 512;  // two workgroups per CU walk the batch's tiles (320 .. 640: the same step rate; more crowd compose out)
@@ -1087,7 +1082,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
     return OFDG_OK;
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
-  if (bgprep_fusable(c)) {
+  if (fusable) {
     hipLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, c->d_err);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;

@@ -654,6 +654,32 @@ def test_background_prep_every_resize_branch(ofdg, oracle, zoom):
     assert ulp_diff(got[2], ef).max() == 0
 
 
+@pytest.mark.parametrize("zoom", [0.8, 1.2])
+def test_background_prep_border_tiles(ofdg, oracle, zoom):
+    """A background that moves further than the margin of its 2W x 2H texture: frame 1 reads the texture up to its borders
+    and beyond (reflection), so the whole texture is prepared - every tile of bgprep_fused_kernel, the ones at the borders
+    included, where the crop leaves the rotated image (zoom < 1: mirrored coordinates, per-texel range tests) - and what
+    frame 1 shows of them is compared with the oracle, bit for bit."""
+    W, H, B = 160, 100, 4
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(3, 384, 256, 9)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    for k, t in enumerate(tasks):
+        b = bps[t.background]
+        b.tex_scale = zoom
+        b.trans_x = (90.0, -85.0, 40.0, -120.0)[k % 4]
+        b.trans_y = (-55.0, 60.0, -70.0, 20.0)[k % 4]
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
+    assert ulp_diff(got[2], ef).max() == 0
+
+
 def test_background_prep_zoom_beyond_the_workspace_is_reported(ofdg, oracle):
     """background_prep = 1 keeps workspaces for crops of the rotated image up to zoom 0.75 (the sampler draws
     0.8 .. 1.2).  A caller's blueprint with a smaller zoom must not be rendered wrongly in silence: the device flags

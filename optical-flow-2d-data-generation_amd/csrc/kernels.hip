@@ -1346,23 +1346,6 @@ __device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSamp
   compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
 }
 
-// Mode 9: the same kernel with the deformation paths compiled in.
-__global__ __launch_bounds__(64) void compose_deform_kernel(
-    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  compose_body<true, false>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
-}
-// Mode 9, W a power of two.
-__global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
-    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
-    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
-    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  compose_body<true, true>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, item_count);
-}
-
 struct Taps4 {
   uint2 t0[kPx], t1[kPx];  // texel pairs of the two rows (mode 2: t0[p].x = the finished pixel)
   uint32_t xf, yf;         // fractions, byte p = pixel p
@@ -1458,13 +1441,14 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 // --------------------------------------------------------------------------
 constexpr int kPre = 2;  // objects of a block whose header / coverage / record are fetched ahead of their visit
 
-template <bool kPow2>
+template <bool kPow2, bool kDeform = false>
 __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
                                               const DevObject* __restrict__ objects, const uint8_t* __restrict__ cov,
                                               int n_strips, int tiles_x, int tiles_y, int W, int H, int use_aa, int bg_pitch, int fg_pitch,
                                               const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
                                               float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
-                                              const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
+                                              const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count,
+                                              const DevCropRef* __restrict__ crops = nullptr) {
   static_assert(kPx == 4, "mask bytes are packed four to a word");
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // raster_kernel has consumed the work list
   // XCD-aware strip mapping (see compose_body)
@@ -1487,12 +1471,13 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   // ---- scalar stage 1: sample (+ background) record and block masks, requested in ONE batch ----
   // (the compiler loads a struct field where its first use is; an empty asm statement that names every value right here
   //  makes that one place: one s_waitcnt for the whole record instead of one per use site)
-  struct SmpRec { int first_object, first_shape; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; } smp;
+  struct SmpRec { int first_object, first_shape; Mat bg_motion, bg_tex_inv; unsigned long long bg_tex_base; int bg_deform; } smp;
   unsigned long long mask0, mask1;
   {
     const DevSample& R = samples[s];
     smp.first_object = R.first_object; smp.first_shape = R.first_shape;
     smp.bg_motion = R.bg_motion; smp.bg_tex_inv = R.bg_tex_inv; smp.bg_tex_base = R.bg_tex_base;
+    smp.bg_deform = kDeform ? R.bg_deform : 0;
     const int nby = (H + kBandRows - 1) / kBandRows;
     const int brow = (ty0 + (sub >> 1) * kBandRows) / kBandRows;
     const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(blockmask + ((size_t)(s * nby + min(brow, nby - 1)) * tiles_x + tx0 / kTileW) * 2);
@@ -1507,6 +1492,8 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   const DevObject* objs = objects + smp.first_object;
   const uint32_t pix = (uint32_t)(y * W + x0);
   const size_t slot_bytes = (size_t)W * H;
+  constexpr int kRecLast = kDeform ? 31 : 25;  // last dword of an object's record a visit needs (31: DevObject.deform)
+  static_assert(offsetof(DevObject, deform) == 31 * 4 && offsetof(DevObject, tex_base) == 24 * 4, "record dwords");
 
   // ---- scalar stage 2: outline slots of the first kPre objects of the mask (sample record: scalar-cache hits) ----
   const uint32_t* shape_tab = reinterpret_cast<const uint32_t*>(samples[s].shape_of);
@@ -1559,7 +1546,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
         if ((mask0 >> (pre_oi[k] - 1)) & 1ull) pre_c0[k] = *reinterpret_cast<const uint32_t*>(c + pix);
         if ((mask1 >> (pre_oi[k] - 1)) & 1ull) pre_c1[k] = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
       }
-      pre_rec[k] = reinterpret_cast<const uint32_t*>(&objs[pre_oi[k]])[min(lane, 25)];  // motion, tex_inv, tex_base
+      pre_rec[k] = reinterpret_cast<const uint32_t*>(&objs[pre_oi[k]])[min(lane, kRecLast)];  // motion, tex_inv, tex_base (mode 9: .. deform)
     }
   }
 
@@ -1585,6 +1572,28 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
       ix = ix + (double)W; iy = iy + (double)H;
       fu[p] = (float)(ix - (double)save_x);
       fv[p] = (float)(iy - (double)save_y);
+    }
+    if constexpr (kDeform) {
+      if (smp.bg_deform > 0) {  // background re-sampled through its (2W x 2H, upscaled) warp crop (DG:670-678, 714-717)
+        const DevCropRef C = crops[smp.bg_deform - 1];
+        const int X0 = x0 + W / 2, Y = y + H / 2;
+#pragma unroll 1
+        for (int p = 0; p < kPx; ++p) {
+          const int X = X0 + p;
+          const float2 iw = crop_pair(C, 1, X, Y);
+          const Taps t = make_taps((float)X + iw.x, (float)Y + iw.y);
+          px1[p] = deform_texel<kPow2>(btex, gb, smp.bg_tex_inv, t, true);
+          // flow: + forward field at the destination (detour coordinates), Neumann
+          double ix = (double)(x0 + p + W / 2) + (double)(-W), iy = by;
+          xform(smp.bg_motion, ix, iy);
+          ix = ix + (double)W; iy = iy + (double)H;
+          if (ix >= 0 && ix < (double)(2 * W) && iy >= 0 && iy < (double)(2 * H)) {
+            const float2 f = linear_neumann2(C, (float)ix, (float)iy);
+            fu[p] += f.x;
+            fv[p] += f.y;
+          }
+        }
+      }
     }
   } else {
 #pragma unroll
@@ -1621,16 +1630,46 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
           if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
           if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
         }
-        recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
+        recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, kRecLast)];
       }
     }
     ++vi;
     static_assert(kPre == 2 || kPre == 1, "the selects above pick between two prefetched sets");
 
+    // mode 9: frame-1 mask bytes (AA and thresholded) of one outline re-sampled through the inverse field
+    // (MovingObjectBase::renderMasks, DG:370-386).  Taps outside the outline's rasterised box read as 0 (the mask is 0
+    // there; outside the frame: Dirichlet).
+    auto warped_mask1 = [&](int shape, const DevShapeFrame& F, const DevCropRef& C, int p, int& aa, int& na) {
+      aa = 0; na = 0;
+      if (!inside || !has1) return;
+      if (F.x0 > F.x1) return;
+      const int x = xv + p;
+      const float2 iw = crop_pair(C, 1, x, yv);
+      const Taps t = make_taps((float)x + iw.x, (float)yv + iw.y);
+      if (!t.ok || t.x + 1 < F.x0 || t.x > F.x1 || t.y + 1 < F.y0 || t.y > F.y1) return;
+      const uint8_t* c = cov + ((size_t)shape * 2 + 1) * slot_bytes;
+      float va[4], vn[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int tx = t.x + i, ty = t.y + j;
+          int cv = 0;
+          if (tx >= F.x0 && tx <= F.x1 && ty >= F.y0 && ty <= F.y1) cv = c[(size_t)ty * W + tx];
+          va[2 * j + i] = (float)aa_byte(cv);
+          vn[2 * j + i] = cv >= 128 ? 255.f : 0.f;
+        }
+      aa = lerp_u8(t, va[0], va[1], va[2], va[3]);
+      na = lerp_u8(t, vn[0], vn[1], vn[2], vn[3]);
+    };
+    int odef = 0;  // mode 9: the object's warp slot + 1 (0: rigid)
+
     uint32_t m0w, m1w, n0w;  // blending masks of the two frames and the thresholded frame-0 mask, byte p = pixel p
     if (!(sh & kShapeComposite)) {
+      if constexpr (kDeform) odef = __builtin_amdgcn_readlane((int)recw, 31);
       // the box touches the block but the outline covers none of this strip's pixels: nothing to mask, sample or blend
-      if (__ballot((c0w | c1w) != 0u) == 0ull) continue;
+      // (mode 9 re-samples a deformed object's frame-1 mask from elsewhere: no such shortcut)
+      if (odef <= 0 && __ballot((c0w | c1w) != 0u) == 0ull) continue;
       m0w = 0; m1w = 0; n0w = 0;
 #pragma unroll
       for (int p = 0; p < kPx; ++p) {
@@ -1640,21 +1679,38 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
         m0w |= (uint32_t)(use_aa ? aa_byte(c0) : na0) << (8 * p);
         m1w |= (uint32_t)(use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0)) << (8 * p);
       }
+      if constexpr (kDeform) {
+        if (odef > 0) {
+          const int shape = smp.first_shape + (int)sh;
+          const DevShapeFrame F1 = frames[shape * 2 + 1];  // (once per visit, not once per pixel)
+          const DevCropRef C = crops[odef - 1];
+          m1w = 0;
+#pragma unroll 1
+          for (int p = 0; p < kPx; ++p) {
+            int aa, na;
+            warped_mask1(shape, F1, C, p, aa, na);
+            m1w |= (uint32_t)(use_aa ? aa : na) << (8 * p);
+          }
+        }
+      }
     } else {
       // composite: sequential fp32 add / subtract over the components (DG:591-646)
       const DevObjectHdr h = *reinterpret_cast<const DevObjectHdr*>(&objs[oi].tex_base);
+      if constexpr (kDeform) odef = h.deform;
       int ua0[kPx], ua1[kPx], un1[kPx], na0[kPx];
 #pragma unroll
       for (int p = 0; p < kPx; ++p) { ua0[p] = ua1[p] = un1[p] = 0; na0[p] = 0; }
       for (int k = 0; k < h.n_shapes; ++k) {
         const uint8_t* c = cov + (size_t)(h.first_shape + k) * 2 * slot_bytes;
         uint32_t k0w = 0, k1w = 0;
+        const DevShapeFrame F0 = frames[(h.first_shape + k) * 2], F1 = frames[(h.first_shape + k) * 2 + 1];
         if (inside) {
           // a component's coverage exists only in the 64 x 8 blocks its own box touches
           const int by0c = ty0 + (sub >> 1) * kBandRows;
-          const DevShapeFrame F0 = frames[(h.first_shape + k) * 2], F1 = frames[(h.first_shape + k) * 2 + 1];
+          int d1 = 0;
+          if constexpr (kDeform) { if (odef > 0) d1 = (int)ceilf(__uint_as_float(*crops[odef - 1].max_bits)) + 2; }
           const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
-          const bool v1 = F1.x0 <= F1.x1 && F1.x0 <= tx0 + kTileW - 1 && F1.x1 >= tx0 && F1.y0 <= by0c + kBandRows - 1 && F1.y1 >= by0c;
+          const bool v1 = F1.x0 <= F1.x1 && F1.x0 - d1 <= tx0 + kTileW - 1 && F1.x1 + d1 >= tx0 && F1.y0 - d1 <= by0c + kBandRows - 1 && F1.y1 + d1 >= by0c;
           if (has0 && v0) k0w = *reinterpret_cast<const uint32_t*>(c + pix);
           if (has1 && v1) k1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
         }
@@ -1662,8 +1718,13 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
 #pragma unroll
         for (int p = 0; p < kPx; ++p) {
           const int c0 = (int)((k0w >> (8 * p)) & 255), c1 = (int)((k1w >> (8 * p)) & 255);
-          const int va0 = aa_byte(c0), va1 = aa_byte(c1);
-          const int vn0 = c0 >= 128 ? 255 : 0, vn1 = c1 >= 128 ? 255 : 0;
+          const int va0 = aa_byte(c0);
+          int va1 = aa_byte(c1);
+          const int vn0 = c0 >= 128 ? 255 : 0;
+          int vn1 = c1 >= 128 ? 255 : 0;
+          if constexpr (kDeform) {
+            if (odef > 0) warped_mask1(h.first_shape + k, F1, crops[odef - 1], p, va1, vn1);  // components warp individually
+          }
           if (additive) {
             ua0[p] = comp_add(ua0[p], va0); ua1[p] = comp_add(ua1[p], va1);
             na0[p] = comp_add(na0[p], vn0); un1[p] = comp_add(un1[p], vn1);
@@ -1681,7 +1742,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
         n0w |= (uint32_t)na0[p] << (8 * p);
       }
       if (__ballot((m0w | m1w | n0w) != 0u) == 0ull) continue;
-      recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, 25)];
+      recw = reinterpret_cast<const uint32_t*>(&objs[oi])[min(lane, kRecLast)];
     }
 
     // the object's matrices: dword i of the record sits in lane i
@@ -1696,7 +1757,22 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
       ti.sx = rec_double(6); ti.shy = rec_double(7); ti.shx = rec_double(8); ti.sy = rec_double(9); ti.tx = rec_double(10); ti.ty = rec_double(11);
       const RowDDA R = make_row<kPow2>(ti, yv, W, g.nshift);
       uint32_t t1[kPx];
-      if constexpr (kPow2) {
+      if (kDeform && odef > 0) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
+        const DevCropRef C = crops[odef - 1];
+#pragma unroll
+        for (int p = 0; p < kPx; ++p) t1[p] = 0;
+#pragma unroll 1
+        for (int p = 0; p < kPx; ++p) {
+          const bool need = ((m1w >> (8 * p)) & 255u) != 0u;
+          if (__ballot(need) == 0ull) continue;
+          const int x = xv + p;
+          const float2 iw = need ? crop_pair(C, 1, x, yv) : make_float2(0.f, 0.f);
+          const Taps t = make_taps((float)x + iw.x, (float)yv + iw.y);
+          const uint32_t o = deform_texel<kPow2>(tex, g, ti, t, need);
+          const uint32_t keep = need ? o : 0u;
+          t1[0] = p == 0 ? keep : t1[0]; t1[1] = p == 1 ? keep : t1[1]; t1[2] = p == 2 ? keep : t1[2]; t1[3] = p == 3 ? keep : t1[3];
+        }
+      } else if constexpr (kPow2) {
         const Taps4 T = taps_issue(tex, g, R, xv, m1w != 0u);
         taps_finish(T, t1);
       } else {
@@ -1723,6 +1799,13 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
           xform(mo, ix, iy);
           fu[p] = (float)(ix - (double)save_x);
           fv[p] = (float)(iy - (double)save_y);
+          if constexpr (kDeform) {
+            if (odef > 0 && ix >= 0 && ix < (double)W && iy >= 0 && iy < (double)H) {  // DG:403-406
+              const float2 f = linear_neumann2(crops[odef - 1], (float)ix, (float)iy);
+              fu[p] += f.x;
+              fv[p] += f.y;
+            }
+          }
         }
       }
     }
@@ -1771,6 +1854,26 @@ __global__ __launch_bounds__(64) void compose_rigid_pow2_kernel(
     float* __restrict__ flow, const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count) {
   compose_rigid<true>(samples, blockmask, objects, cov, n_strips, tiles_x, tiles_y, W, H, use_aa, bg_pitch, fg_pitch, pool, bgpool, img0, img1,
                       flow, frames, item_count);
+}
+
+// Mode 9: the same body with the deformation paths compiled in (masks, textures and flow of deformed objects and backgrounds
+// re-sampled through their warp crops).
+__global__ __launch_bounds__(64) void compose_deform_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_rigid<false, true>(samples, blockmask, objects, cov, (int)gridDim.x, dm.tiles_x, dm.tiles_y, dm.W, dm.H, dm.use_aa, dm.bg_pitch, dm.fg_pitch,
+                             pool, bgpool, img0, img1, flow, frames, item_count, crops);
+}
+// Mode 9, W a power of two.
+__global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
+    RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
+    const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
+    const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
+    const DevShapeFrame* __restrict__ frames, const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
+  compose_rigid<true, true>(samples, blockmask, objects, cov, (int)gridDim.x, dm.tiles_x, dm.tiles_y, dm.W, dm.H, dm.use_aa, dm.bg_pitch, dm.fg_pitch,
+                            pool, bgpool, img0, img1, flow, frames, item_count, crops);
 }
 
 // --------------------------------------------------------------------------

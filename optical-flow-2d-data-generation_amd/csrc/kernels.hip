@@ -832,79 +832,6 @@ __device__ __forceinline__ uint32_t bilerp_rgb(uint2 t0, uint2 t1, uint32_t xf, 
   const uint32_t g = g0 * ifx + g1 * xf + 32768u;
   return (b >> 16) | ((g >> 8) & 0xFF00u) | (r & 0xFF0000u);
 }
-template <bool kPow2>
-__device__ __forceinline__ void sample4(const uint32_t* __restrict__ tex, const WarpGeom& g, const RowDDA& R, int i0,
-                                        bool need, uint32_t out[kPx]) {
-  if constexpr (!kPow2) {
-#pragma unroll
-    for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear(tex, g, R, i0 + p);
-  } else {
-    int xh[kPx], yh[kPx];
-    {
-      int ax = (i0 + 1) * R.rx + g.tw - 1, bx = R.x1 - 129 + i0 * R.lx;  // dda_at(...) - 128
-      int ay = (i0 + 1) * R.ry + g.tw - 1, by = R.y1 - 129 + i0 * R.ly;
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        xh[p] = bx + (ax >> g.nshift); yh[p] = by + (ay >> g.nshift);
-        ax += R.rx; bx += R.lx; ay += R.ry; by += R.ly;
-      }
-    }
-    const bool in_range = (unsigned)(xh[0] >> 8) <= (unsigned)(g.tw - 2) && (unsigned)(xh[kPx - 1] >> 8) <= (unsigned)(g.tw - 2) &&
-                          (unsigned)(yh[0] >> 8) <= (unsigned)(g.th - 2) && (unsigned)(yh[kPx - 1] >> 8) <= (unsigned)(g.th - 2);
-    if (__ballot(need && !in_range) == 0ull) {
-      const char* base = reinterpret_cast<const char*>(tex);
-      const uint32_t pitch4 = (uint32_t)g.pitch * 4u;
-      uint2 t0[kPx], t1[kPx];
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        // (lanes that do not need the result may point anywhere: clamp them to texel 0)
-        const uint32_t off = need ? ((uint32_t)(yh[p] >> 8) * (uint32_t)g.pitch + (uint32_t)(xh[p] >> 8)) * 4u : 0u;
-        t0[p] = *reinterpret_cast<const uint2*>(base + off);
-        t1[p] = *reinterpret_cast<const uint2*>(base + off + pitch4);
-      }
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) out[p] = bilerp_rgb(t0[p], t1[p], (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
-    } else {
-      // Some lane reflects at a texture border.  As long as every coordinate lies within one
-      // period of the image (|v| < 2 * size: always, unless the motion is absurd) the reflection
-      // is two selects per axis and all 16 taps of the lane are still in flight together;
-      // otherwise the general interpolator, pixel by pixel.
-      const int tw2 = g.tw2, th2 = g.th2;
-      bool one_period = true;
-#pragma unroll
-      for (int p = 0; p < kPx; p += kPx - 1)
-        one_period = one_period && (unsigned)((xh[p] >> 8) + tw2) < 3u * (unsigned)tw2 - 1u && (unsigned)((yh[p] >> 8) + th2) < 3u * (unsigned)th2 - 1u;
-      if (__ballot(need && !one_period) == 0ull) {
-        auto reflect = [](int v, int size, int size2) {  // wrap_mode_reflect for -size2 <= v < 2 * size2
-          int m = v < 0 ? v + size2 : v;
-          m = m >= size2 ? m - size2 : m;
-          return m >= size ? size2 - 1 - m : m;
-        };
-        uint32_t p00[kPx], p10[kPx], p01[kPx], p11[kPx];
-#pragma unroll
-        for (int p = 0; p < kPx; ++p) {
-          const int xl = need ? xh[p] >> 8 : 0, yl = need ? yh[p] >> 8 : 0;
-          const uint32_t xa = (uint32_t)reflect(xl, g.tw, tw2), xb = (uint32_t)reflect(xl + 1, g.tw, tw2);
-          const uint32_t ra = (uint32_t)reflect(yl, g.th, th2) * (uint32_t)g.pitch, rb = (uint32_t)reflect(yl + 1, g.th, th2) * (uint32_t)g.pitch;
-          p00[p] = tex[ra + xa]; p10[p] = tex[ra + xb]; p01[p] = tex[rb + xa]; p11[p] = tex[rb + xb];
-        }
-#pragma unroll
-        for (int p = 0; p < kPx; ++p)
-          out[p] = bilerp_rgb(make_uint2(p00[p], p10[p]), make_uint2(p01[p], p11[p]), (uint32_t)xh[p] & 255u, (uint32_t)yh[p] & 255u);
-      } else {
-#pragma unroll 1
-        for (int p = 0; p < kPx; ++p) out[p] = sample_bilinear<true>(tex, g, R, i0 + p);
-      }
-    }
-  }
-}
-
-// One thread renders kPx horizontally adjacent pixels; a 256-thread workgroup a 64 x 16
-// tile.  Objects are visited in painter's order (ascending ID) through the tile's object
-// bit mask; their coverage comes from the slots raster_kernel filled (valid over every
-// touched tile, zero outside the outlines).
-// Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799,
-// computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
 // CImg<float>::_linear_atXY (Neumann): clamp, nx = dx > 0 ? x+1 : x, fp32 polynomial.
 template <class Ptr>
 __device__ __forceinline__ float linear_neumann(Ptr img, int w, int h, float fx, float fy) {
@@ -1013,345 +940,12 @@ __device__ __forceinline__ uint32_t deform_texel(const uint32_t* __restrict__ te
   return o;
 }
 
-// Body of the compose kernel; kDeform adds the mode-9 paths (masks, textures and flow
-// re-sampled through per-object warp crops).
-template <bool kDeform, bool kPow2>
-__device__ __forceinline__ void compose_tile(const RenderDims& dm, const DevSample* __restrict__ samples,
-                                             const DevObject* __restrict__ objects,
-                                             const unsigned long long* __restrict__ blockmask,
-                                             const uint8_t* __restrict__ cov,
-                                             const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
-                                             float* __restrict__ img0, float* __restrict__ img1,
-                                             float* __restrict__ flow,
-                                             const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops, int bid, int tid) {
-  const int tiles = dm.tiles_x * dm.tiles_y;
-  const int s = bid / tiles;
-  if (s >= dm.n_samples) return;
-  const int t = bid - s * tiles;
-  const int ty0 = (t / dm.tiles_x) * kTileH, tx0 = (t % dm.tiles_x) * kTileW;
-  const int W = dm.W, H = dm.H;
-  const int x0 = tx0 + (tid & 15) * kPx;
-  const int y = ty0 + (tid >> 4);
-  const bool inside = (x0 < W) && (y < H);  // W % 4 == 0 is required by the host
-
-  const DevSample smp = samples[s];
-  const DevObject* objs = objects + smp.first_object;
-  // Every wave covers 4 rows: waves 0,1 the upper 64 x 8 block of the tile, waves 2,3 the
-  // lower.  Which objects can touch the block: the block's mask pair (geom_kernel), one
-  // scalar load that depends on nothing but the block index.
-  unsigned long long mask0, mask1;
-  {
-    const int nbx = dm.tiles_x, nby = (H + kBandRows - 1) / kBandRows;
-    const int brow = __builtin_amdgcn_readfirstlane((ty0 + (tid >> 7) * kBandRows) / kBandRows);
-    const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(blockmask + ((size_t)(s * nby + min(brow, nby - 1)) * nbx + tx0 / kTileW) * 2);
-    mask0 = mm.x; mask1 = mm.y;
-  }
-  unsigned long long omask = mask0 | mask1;
-
-  const uint32_t pix = (uint32_t)(y * W + x0);  // offset inside one coverage slot
-  const size_t slot_bytes = (size_t)W * H;
-  uint32_t px0[kPx], px1[kPx];  // frames, packed B | G<<8 | R<<16
-  float fu[kPx], fv[kPx];
-
-  // ---- background (object 0): masks are all 255, so frames start as its textures ----
-  {
-    const DevObject& B = objs[0];
-    const uint32_t* tex = bgpool + B.tex_base;  // origin of the 2W x 2H texture (centre crop of the pool image, or the sample's prepared one)
-    WarpGeom g;
-    g.tw = 2 * W; g.th = 2 * H; g.tw2 = 4 * W; g.th2 = 4 * H;
-    g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
-    g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
-    g.nshift = ((g.tw & (g.tw - 1)) == 0) ? (31 - __clz(g.tw)) : -1;
-    g.pitch = dm.bg_pitch;
-    const int yy = y + H / 2, xx = x0 + W / 2;
-    if (inside) {
-      // frame 0: identity warp == copy, then the crop at (W/2, H/2)  (DG:667-668, 680)
-      const uint4 t0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(yy * g.pitch + xx));
-      const uint32_t tt[4] = {t0.x, t0.y, t0.z, t0.w};
-      const RowDDA R = make_row<kPow2>(B.tex_inv, yy, g.tw, g.nshift);
-      // MovingObjectBackground::getPointFlow (DG:692-718): T(-W,-H), motion, T(W,H)
-      const double by = (double)(y + H / 2) + (double)(-H);
-      sample4<kPow2>(tex, g, R, xx, true, px1);
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        px0[p] = tt[p] & 0x00FFFFFFu;
-        double ix = (double)(x0 + p + W / 2), iy = by;
-        const float save_x = (float)(x0 + p + W / 2), save_y = (float)(y + H / 2);
-        ix = ix + (double)(-W);
-        xform(B.motion, ix, iy);
-        ix = ix + (double)W; iy = iy + (double)H;
-        fu[p] = (float)(ix - (double)save_x);
-        fv[p] = (float)(iy - (double)save_y);
-      }
-      if constexpr (kDeform) {
-        if (B.deform > 0) {  // background re-sampled through its (2W x 2H, upscaled) warp crop (DG:670-678, 714-717)
-          const DevCropRef C = crops[B.deform - 1];
-          const int X0 = x0 + W / 2, Y = y + H / 2;
-#pragma unroll 1
-          for (int p = 0; p < kPx; ++p) {
-            const int X = X0 + p;
-            const float2 iw = crop_pair(C, 1, X, Y);
-            const Taps t = make_taps((float)X + iw.x, (float)Y + iw.y);
-            px1[p] = deform_texel<kPow2>(tex, g, B.tex_inv, t, true);
-            // flow: + forward field at the destination (detour coordinates), Neumann
-            double ix = (double)(x0 + p + W / 2) + (double)(-W), iy = by;
-            xform(B.motion, ix, iy);
-            ix = ix + (double)W; iy = iy + (double)H;
-            if (ix >= 0 && ix < (double)(2 * W) && iy >= 0 && iy < (double)(2 * H)) {
-              const float2 f = linear_neumann2(C, (float)ix, (float)iy);
-              fu[p] += f.x;
-              fv[p] += f.y;
-            }
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        fu[p] = fv[p] = 0.f;
-        px0[p] = px1[p] = 0;
-      }
-    }
-  }
-
-  // ---- foreground objects in z-order ----
-  WarpGeom g;
-  g.tw = W; g.th = H; g.tw2 = 2 * W; g.th2 = 2 * H;
-  g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
-  g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
-  g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
-  g.pitch = dm.fg_pitch;
-
-  while (omask) {
-    const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
-    omask &= omask - 1;
-    const DevObject& O = objs[oi];
-    const bool has0 = (mask0 >> (oi - 1)) & 1ull, has1 = (mask1 >> (oi - 1)) & 1ull;  // wave-uniform
-
-    int m0[kPx], m1[kPx];   // blending masks for the two frames
-    int na0[kPx];           // thresholded frame-0 mask (index image)
-    // mode 9: frame-1 mask bytes (AA and thresholded) of one outline re-sampled through the
-    // inverse field (MovingObjectBase::renderMasks, DG:370-386).  Taps outside the outline's
-    // rasterised box read as 0 (the mask is 0 there; outside the frame: Dirichlet).
-    auto warped_mask1 = [&](int shape, const DevShapeFrame& F, const DevCropRef& C, int p, int& aa, int& na) {
-      aa = 0; na = 0;
-      if (!inside || !has1) return;
-      if (F.x0 > F.x1) return;
-      const int x = x0 + p;
-      const float2 iw = crop_pair(C, 1, x, y);
-      const Taps t = make_taps((float)x + iw.x, (float)y + iw.y);
-      if (!t.ok || t.x + 1 < F.x0 || t.x > F.x1 || t.y + 1 < F.y0 || t.y > F.y1) return;
-      const uint8_t* c = cov + ((size_t)shape * 2 + 1) * slot_bytes;
-      float va[4], vn[4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int tx = t.x + i, ty = t.y + j;
-          int cv = 0;
-          if (tx >= F.x0 && tx <= F.x1 && ty >= F.y0 && ty <= F.y1) cv = c[(size_t)ty * W + tx];
-          va[2 * j + i] = (float)aa_byte(cv);
-          vn[2 * j + i] = cv >= 128 ? 255.f : 0.f;
-        }
-      aa = lerp_u8(t, va[0], va[1], va[2], va[3]);
-      na = lerp_u8(t, vn[0], vn[1], vn[2], vn[3]);
-    };
-
-    if (O.kind == 1) {
-      const uint8_t* c = cov + (size_t)O.first_shape * 2 * slot_bytes;
-      uint32_t c0w = 0, c1w = 0;
-      if (inside) {
-        if (has0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
-        if (has1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
-      }
-      // the box touches the block but the outline covers none of this strip's pixels (about
-      // half of the visits): nothing to mask, sample or blend
-      bool moved_mask = false;
-      if constexpr (kDeform) moved_mask = O.deform > 0;  // mode 9 re-samples the frame-1 mask from elsewhere
-      if (!moved_mask && __ballot((c0w | c1w) != 0u) == 0ull) continue;
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
-        na0[p] = c0 >= 128 ? 255 : 0;
-        m0[p] = dm.use_aa ? aa_byte(c0) : na0[p];
-        m1[p] = dm.use_aa ? aa_byte(c1) : (c1 >= 128 ? 255 : 0);
-      }
-      if constexpr (kDeform) {
-        if (O.deform > 0) {
-          const DevShapeFrame F1 = frames[O.first_shape * 2 + 1];  // (once per visit, not once per pixel)
-          const DevCropRef C = crops[O.deform - 1];
-#pragma unroll 1
-          for (int p = 0; p < kPx; ++p) {
-            int aa, na;
-            warped_mask1(O.first_shape, F1, C, p, aa, na);
-            m1[p] = dm.use_aa ? aa : na;
-          }
-        }
-      }
-    } else {
-      // composite: sequential fp32 add / subtract over the components (DG:591-646)
-      int ua0[kPx], ua1[kPx], un1[kPx];
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) { ua0[p] = ua1[p] = un1[p] = 0; na0[p] = 0; }
-      for (int k = 0; k < O.n_shapes; ++k) {
-        const uint8_t* c = cov + (size_t)(O.first_shape + k) * 2 * slot_bytes;
-        uint32_t c0w = 0, c1w = 0;
-        const DevShapeFrame F0 = frames[(O.first_shape + k) * 2], F1 = frames[(O.first_shape + k) * 2 + 1];
-        if (inside) {
-          // a component's coverage exists only in the 64 x 8 blocks its own box touches
-          const int by0c = ty0 + (tid >> 7) * kBandRows;
-          int d1 = 0;
-          if constexpr (kDeform) { if (O.deform > 0) d1 = (int)ceilf(__uint_as_float(*crops[O.deform - 1].max_bits)) + 2; }
-          const bool v0 = F0.x0 <= F0.x1 && F0.x0 <= tx0 + kTileW - 1 && F0.x1 >= tx0 && F0.y0 <= by0c + kBandRows - 1 && F0.y1 >= by0c;
-          const bool v1 = F1.x0 <= F1.x1 && F1.x0 - d1 <= tx0 + kTileW - 1 && F1.x1 + d1 >= tx0 && F1.y0 - d1 <= by0c + kBandRows - 1 && F1.y1 + d1 >= by0c;
-          if (has0 && v0) c0w = *reinterpret_cast<const uint32_t*>(c + pix);
-          if (has1 && v1) c1w = *reinterpret_cast<const uint32_t*>(c + slot_bytes + pix);
-        }
-        const bool additive = (O.additive >> k) & 1u;
-#pragma unroll
-        for (int p = 0; p < kPx; ++p) {
-          const int c0 = (int)((c0w >> (8 * p)) & 255), c1 = (int)((c1w >> (8 * p)) & 255);
-          const int va0 = aa_byte(c0);
-          int va1 = aa_byte(c1);
-          const int vn0 = c0 >= 128 ? 255 : 0;
-          int vn1 = c1 >= 128 ? 255 : 0;
-          if constexpr (kDeform) {
-            if (O.deform > 0) warped_mask1(O.first_shape + k, F1, crops[O.deform - 1], p, va1, vn1);  // components warp individually
-          }
-          if (additive) {
-            ua0[p] = comp_add(ua0[p], va0); ua1[p] = comp_add(ua1[p], va1);
-            na0[p] = comp_add(na0[p], vn0); un1[p] = comp_add(un1[p], vn1);
-          } else {
-            ua0[p] = comp_sub(ua0[p], va0); ua1[p] = comp_sub(ua1[p], va1);
-            na0[p] = comp_sub(na0[p], vn0); un1[p] = comp_sub(un1[p], vn1);
-          }
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        m0[p] = dm.use_aa ? ua0[p] : na0[p];
-        m1[p] = dm.use_aa ? ua1[p] : un1[p];
-      }
-    }
-
-    // the masks wait for the texture taps as three packed words (byte p = pixel p), not 12 registers
-    static_assert(kPx == 4, "mask bytes are packed four to a word");
-    const uint32_t m0w = (uint32_t)m0[0] | ((uint32_t)m0[1] << 8) | ((uint32_t)m0[2] << 16) | ((uint32_t)m0[3] << 24);
-    const uint32_t m1w = (uint32_t)m1[0] | ((uint32_t)m1[1] << 8) | ((uint32_t)m1[2] << 16) | ((uint32_t)m1[3] << 24);
-    const uint32_t n0w = (uint32_t)na0[0] | ((uint32_t)na0[1] << 8) | ((uint32_t)na0[2] << 16) | ((uint32_t)na0[3] << 24);
-    const uint32_t any0 = m0w, any1 = m1w, anyn = n0w;
-    const uint32_t* tex = pool + O.tex_base;  // origin of the W x H centre crop
-    // frame 0 texture: identity warp == the crop itself (DG:339-340).  The load is issued here
-    // and consumed after the frame-1 taps: one memory round trip for both frames.
-    uint4 q0 = make_uint4(0, 0, 0, 0);
-    if (any0) q0 = *reinterpret_cast<const uint4*>(tex + (uint32_t)(y * g.pitch + x0));
-    uint32_t t1[kPx] = {0, 0, 0, 0};
-    bool deform_tex = false;
-    if constexpr (kDeform) deform_tex = (O.deform > 0);
-    if (any1 && !deform_tex) {
-      const RowDDA R = make_row<kPow2>(O.tex_inv, y, W, g.nshift);
-      sample4<kPow2>(tex, g, R, x0, true, t1);
-    }
-    if constexpr (kDeform) {
-      if (any1 && deform_tex) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
-        const DevCropRef C = crops[O.deform - 1];
-#pragma unroll 1
-        for (int p = 0; p < kPx; ++p) {
-          const bool need = ((m1w >> (8 * p)) & 255u) != 0u;
-          if (__ballot(need) == 0ull) continue;
-          const int x = x0 + p;
-          const float2 iw = need ? crop_pair(C, 1, x, y) : make_float2(0.f, 0.f);
-          const Taps t = make_taps((float)x + iw.x, (float)y + iw.y);
-          const uint32_t o = deform_texel<kPow2>(tex, g, O.tex_inv, t, need);
-          if (need) t1[p] = o;
-        }
-      }
-    }
-    if (any1) {
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (m1w >> (8 * p)) & 255u);  // m == 0 leaves the pixel as is
-    }
-    if (any0) {
-      const uint32_t tt[4] = {q0.x, q0.y, q0.z, q0.w};
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) px0[p] = blend_px(px0[p], tt[p], (m0w >> (8 * p)) & 255u);
-    }
-    if (anyn) {
-      // MovingObjectBase::getPointFlow (DG:388-407) for pixels this object now owns
-#pragma unroll
-      for (int p = 0; p < kPx; ++p) {
-        if (((n0w >> (8 * p)) & 255u) == 255u) {
-          double ix = (double)(x0 + p), iy = (double)y;
-          const float save_x = (float)(x0 + p), save_y = (float)y;
-          xform(O.motion, ix, iy);
-          fu[p] = (float)(ix - (double)save_x);
-          fv[p] = (float)(iy - (double)save_y);
-          if constexpr (kDeform) {
-            if (O.deform > 0 && ix >= 0 && ix < (double)W && iy >= 0 && iy < (double)H) {  // DG:403-406
-              const float2 f = linear_neumann2(crops[O.deform - 1], (float)ix, (float)iy);
-              fu[p] += f.x;
-              fv[p] += f.y;
-            }
-          }
-        }
-      }
-    }
-  }
-
-  if (!inside) return;
-  // u8 -> float planes (DG:1229-1245); streaming 16-byte stores, never re-read
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const size_t plane = (size_t)W * H;
-  const size_t o = (size_t)y * W + x0;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    f32x4 a = {(float)((px0[0] >> (8 * c)) & 255u), (float)((px0[1] >> (8 * c)) & 255u),
-               (float)((px0[2] >> (8 * c)) & 255u), (float)((px0[3] >> (8 * c)) & 255u)};
-    f32x4 b = {(float)((px1[0] >> (8 * c)) & 255u), (float)((px1[1] >> (8 * c)) & 255u),
-               (float)((px1[2] >> (8 * c)) & 255u), (float)((px1[3] >> (8 * c)) & 255u)};
-    __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(img0 + ((size_t)s * 3 + c) * plane + o));
-    __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(img1 + ((size_t)s * 3 + c) * plane + o));
-  }
-  f32x4 u = {fu[0], fu[1], fu[2], fu[3]};
-  f32x4 v = {fv[0], fv[1], fv[2], fv[3]};
-  __builtin_nontemporal_store(u, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 0) * plane + o));
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(flow + ((size_t)s * 2 + 1) * plane + o));
-}
-
-template <bool kDeform, bool kPow2>
-__device__ __forceinline__ void compose_body(const RenderDims& dm, const DevSample* __restrict__ samples,
-                                             const DevObject* __restrict__ objects,
-                                             const unsigned long long* __restrict__ blockmask,
-                                             const uint8_t* __restrict__ cov,
-                                             const uint32_t* __restrict__ pool, const uint32_t* __restrict__ bgpool,
-                                             float* __restrict__ img0, float* __restrict__ img1,
-                                             float* __restrict__ flow,
-                                             const DevShapeFrame* __restrict__ frames,
-                                             const DevCropRef* __restrict__ crops, int* __restrict__ item_count) {
-  // raster_kernel has consumed the work list: reset the counter for this slot's next launch
-  if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;
-  // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch).  Every XCD takes
-  // every 8th run of 32 consecutive strips (= one 64 x 16 tile row of 8 tiles): neighbouring
-  // strips share their background rows, coverage and object records in that XCD's L2, and the
-  // foreground-heavy samples are spread over all XCDs.
-  const int nblk = gridDim.x;
-  int wg = blockIdx.x;
-  if (wg < (nblk & ~255)) {
-    const int xcd = wg & 7, slot = wg >> 3;
-    wg = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31);
-  }
-  // one wave per workgroup: a finished wave's slot is refilled at once, not when the slowest
-  // of four sibling waves retires
-  compose_tile<kDeform, kPow2>(dm, samples, objects, blockmask, cov, pool, bgpool, img0, img1, flow, frames, crops, wg >> 2, (wg & 3) * 64 + (int)threadIdx.x);
-}
-
 struct Taps4 {
   uint2 t0[kPx], t1[kPx];  // texel pairs of the two rows (mode 2: t0[p].x = the finished pixel)
   uint32_t xf, yf;         // fractions, byte p = pixel p
   int mode;                // 0 paired loads, 1 reflected single loads, 2 general interpolator (nothing issued)
 };
-// first half of sample4<true>: addresses + loads
+// the four frame-1 texels of a lane (span_image_filter_rgb_bilinear along the row's interpolator), first half: addresses + loads
 __device__ __forceinline__ Taps4 taps_issue(const uint32_t* __restrict__ tex_, const WarpGeom& g, const RowDDA& R, int i0, bool need) {
   const uint32_t* __restrict__ tex = uniform_ptr(tex_);
   Taps4 T;
@@ -1428,8 +1022,12 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 }
 
 // --------------------------------------------------------------------------
-// compose_rigid_kernel: the compose kernel of the rigid modes (every mode but 9), written around the
-// latency of a strip: what a wave waits for is fetched in as few dependent round trips as the data allows.
+// compose_rigid: the compose kernel of every mode (kDeform compiles the mode-9 paths in), written around the latency of a
+// strip: what a wave waits for is fetched in as few dependent round trips as the data allows.  One single-wave workgroup
+// renders a 64 x 4 strip, a lane kPx = 4 horizontally adjacent pixels; objects are visited in painter's order (ascending
+// ID) through the block's object masks; their coverage comes from the slots raster_kernel filled (valid over every
+// touched block, zero outside the outlines).
+// Reference: Process_TaskBucket DG:1216-1245, blitObject DG:762-799, computeFlowImage/getPointFlow DG:801-818, 388-407, 692-718.
 //   scalar stage 1   sample record (background matrices inline) + the block's object masks   [kernel arguments are
 //                    preloaded into SGPRs: leading scalar parameters, -amdgpu-kernarg-preload-count]
 //   scalar stage 2   headers (coverage slot, texture origin, kind) of the first kPre objects of the mask
@@ -1437,7 +1035,11 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 //                    dword i; the matrices are moved to SGPRs with v_readlane when the visit needs them)
 //   per visit        texture taps of both frames (one round trip), blend, flow
 //   stores           8 fp32 planes, 16-byte non-temporal stores
-// Same arithmetic as compose_tile (the mode-9 kernels), bit for bit.
+// Mode 9 (kDeform): a deformed object's frame-1 mask, its frame-1 texture and its flow - and the same for a deformed
+// background - are re-sampled through the object's warp crop, pixel by pixel, inside the same visit (DG:370-386, 341-345,
+// 403-406, 670-678, 714-717); everything rigid in a mode-9 batch takes the rigid path above.  120 VGPRs = four waves per
+// SIMD (the former separate mode-9 body: 158 = three); sharing the displacement loads between the mask and the texture
+// of a visit costs the fourth wave (149 VGPRs) and more than it saves.
 // --------------------------------------------------------------------------
 constexpr int kPre = 2;  // objects of a block whose header / coverage / record are fetched ahead of their visit
 
@@ -1451,7 +1053,10 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
                                               const DevCropRef* __restrict__ crops = nullptr) {
   static_assert(kPx == 4, "mask bytes are packed four to a word");
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // raster_kernel has consumed the work list
-  // XCD-aware strip mapping (see compose_body)
+  // XCD-aware strip mapping: blocks b and b + 8 share an XCD (round-robin dispatch).  Every XCD takes every 8th run of 32
+  // consecutive strips (= one 64 x 16 tile row of 8 tiles): neighbouring strips share their background rows, coverage and
+  // object records in that XCD's L2, and the foreground-heavy samples are spread over all XCDs.  One wave per workgroup: a
+  // finished wave's slot is refilled at once, not when the slowest of four sibling waves retires.
   int wg = blockIdx.x;
   if (wg < (n_strips & ~255)) {
     const int xcd = wg & 7, slot = wg >> 3;

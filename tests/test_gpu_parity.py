@@ -524,6 +524,33 @@ def test_mode9_render_matches_oracle_with_uploaded_crops(ofdg, oracle, use_aa):
     assert np.array_equal(r0, e0) and not np.array_equal(r1, e1) and not np.array_equal(np.nan_to_num(rf), np.nan_to_num(ef))
 
 
+@pytest.mark.parametrize("size,prep", [((160, 100), 0), ((128, 96), 1), ((160, 100), 1)], ids=["any-width", "prepared-backgrounds", "any-width-prepared"])
+def test_mode9_render_any_width_and_prepared_backgrounds(ofdg, oracle, size, prep):
+    """Mode 9 through the kernel for widths that are no power of two (compose_deform_kernel: division-based
+    interpolators, the general bilinear path), and on prepared backgrounds (background_prep = 1: a deformed background
+    re-samples the sample's own 2W x 2H texture, all of which is then prepared) - bit-exact against the oracle."""
+    W, H = size
+    B = 6
+    crops = oracle.warp_crops(W, H, seed=5)
+    crops = crops[::5][:6] * 4.0
+    p = ofdg.default_params(width=W, height=H, mode=9, background_prep=prep)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(4, 2 * W + 64, 2 * H + 56, 7)
+    g.warp_upload(crops)
+    pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(9, W, H).next(B)
+    deform = sum(bps[t.background].do_warpfield_deformation for t in tasks) + \
+        sum(bps[t.first_object + i].do_warpfield_deformation for t in tasks for i in range(t.n_objects))
+    assert deform >= 6, "the test batch should exercise deformations"
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = prep
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, pool, warp_crops=crops, reuse=2)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), "image1 differs at %d px" % (got[1] != e1).sum()
+    assert nan_equal_ulp(got[2], ef) == 0
+
+
 def test_mode9_field_generation_equals_oracle(ofdg, oracle):
     """Device warp-field generation (displacer sampling, 17 self-composition passes, NaN flags, clamp, crops;
     WarpFields.cpp:337-455, 617-633) vs the oracle on the same seeded displacers.  The Gaussian weight's expf is

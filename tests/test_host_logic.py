@@ -401,3 +401,16 @@ def test_shards_tile_the_sample_stream(ofdg, world, batch):
             seen[first:first + batch] += 1
     assert (seen == 1).all()
     assert ofdg.shard_first_index(0, batch, world, world) == -1 and ofdg.shard_first_index(-1, batch, world, 0) == -1
+
+
+def test_tile_index_division_by_reciprocal_is_exact():
+    """bgprep_fused_kernel splits a tile's texel-pair index k into (row, pair) with k // pairs computed as
+    (k * (2^20 // pairs + 1)) >> 20 (both factors below 2^24: one 24-bit multiply).  Exact over the whole range the kernel
+    can reach: pairs <= 45 (a 90-texel LDS row), k < pairs * 48 rows."""
+    for pairs in range(1, 46):
+        inv = (1 << 20) // pairs + 1
+        assert inv < (1 << 24)
+        for k in range(pairs * 48 + 1):
+            assert k * inv < (1 << 32)
+            assert (k * inv) >> 20 == k // pairs
+

@@ -14,7 +14,7 @@ if os.environ.get("ARMS"):
 outs = [ofdg.alloc_outputs(B, H, W) for _ in range(16)]
 st = torch.cuda.current_stream().cuda_stream
 for arm in arms:
-    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, num_objects=16, batch_size=B, sampler=1, seed=20261003, **arm))
+    g = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=5, num_objects=16, batch_size=B, sampler=1, seed=20261003, background_prep=int(os.environ.get("BGPREP", "0")), **arm))
     g.pool_synthetic(1000, 1024, 768, 2024)
     nb = min(16, 2 * g.num_chains())
     k = 0

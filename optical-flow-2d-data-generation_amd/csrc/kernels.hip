@@ -1360,7 +1360,6 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
     if (__ballot(m1w != 0u)) {
       Mat ti;
       ti.sx = rec_double(6); ti.shy = rec_double(7); ti.shx = rec_double(8); ti.sy = rec_double(9); ti.tx = rec_double(10); ti.ty = rec_double(11);
-      const RowDDA R = make_row<kPow2>(ti, yv, W, g.nshift);
       uint32_t t1[kPx];
       if (kDeform && odef > 0) {  // applyWarpFieldToTexture(getTransformedTexture(tex, motion), iwarp) (DG:341-345)
         const DevCropRef C = crops[odef - 1];
@@ -1377,12 +1376,15 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
           const uint32_t keep = need ? o : 0u;
           t1[0] = p == 0 ? keep : t1[0]; t1[1] = p == 1 ? keep : t1[1]; t1[2] = p == 2 ? keep : t1[2]; t1[3] = p == 3 ? keep : t1[3];
         }
-      } else if constexpr (kPow2) {
-        const Taps4 T = taps_issue(tex, g, R, xv, m1w != 0u);
-        taps_finish(T, t1);
       } else {
+        const RowDDA R = make_row<kPow2>(ti, yv, W, g.nshift);
+        if constexpr (kPow2) {
+          const Taps4 T = taps_issue(tex, g, R, xv, m1w != 0u);
+          taps_finish(T, t1);
+        } else {
 #pragma unroll
-        for (int p = 0; p < kPx; ++p) t1[p] = m1w ? sample_bilinear(tex, g, R, xv + p) : 0u;
+          for (int p = 0; p < kPx; ++p) t1[p] = m1w ? sample_bilinear(tex, g, R, xv + p) : 0u;
+        }
       }
 #pragma unroll
       for (int p = 0; p < kPx; ++p) px1[p] = blend_px(px1[p], t1[p], (m1w >> (8 * p)) & 255u);  // m == 0 leaves the pixel as is

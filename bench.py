@@ -2,7 +2,10 @@
 """Benchmark of the hot path: training samples/s (image0 + image1 + flow) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}]
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
+    N > 1, started by hand: the script launches its N ranks itself (one child process per GPU with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment; the parent never touches the GPU, relays rank 0's JSON
+    line and exits non-zero if any rank does).  Started by `python -m torch.distributed.run --nproc-per-node N ...`
+    (WORLD_SIZE already set) it is one of the ranks.
 
 Default workload = BASELINE.json configs[1] (--config 2): FlyingChairs mode 5, 512x384, batch 32 per GPU,
 16 objects, affine-only motion, AA on, synthetic 1000 x 1024x768 texture pool.  The other BASELINE
@@ -27,9 +30,12 @@ header + texture index table (ofdg_comm_bcast_setup, csrc/comm.cpp); the JSON li
 ncclCommCount says, `shards` = every rank's first global index of steps 0 and 1).  If the native start-up fails the run
 exits non-zero on every rank (--allow-fallback: the same header over torch.distributed instead, and the line says so).
 
-`reference_equivalent` in the same line: the same workload with background_prep = 1 - Texture::getRandomizedCrop(2W, 2H,
-rot, zoom, shift) on every sample's background, which the reference runs per sample (DataGenerator.cpp:1186-1192) and
-the headline skips - on the GPU and in the CPU-baseline leg.
+The headline `value` (and the `cpu_baseline` next to it) is the REFERENCE-EQUIVALENT workload: background_prep = 1 -
+Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) on every sample's background, which the reference runs per sample
+(DataGenerator.cpp:1186-1192) - the CImg chain stage by stage on the device.  `centre_crop_backgrounds` in the same line is
+the lighter form (background_prep = 0: every background is the centre crop of its pool image; the headline of rounds 1-3),
+measured after the headline context is closed.  --background-prep 0 makes that form the headline instead (and says so in
+`config`).
 """
 import argparse
 import importlib
@@ -121,7 +127,7 @@ def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128, background_prep=0
                       % (mode, W, H, nobj or "16-23", n_pool, cfg["pool"][0], res["faithful_all"]["threads"], total)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -132,96 +138,203 @@ def main():
     ap.add_argument("--sampler", choices=("counter", "resident"), default=None)
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: if the native RCCL start-up fails, broadcast the header over torch.distributed instead of exiting")
-    ap.add_argument("--no-reference-equivalent", action="store_true", help="skip the background_prep = 1 pass")
-    ap.add_argument("--background-prep", action="store_true",
-                    help="apply Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) to every background (DataGenerator.cpp:1186-1192)")
-    args = ap.parse_args()
-    cfg = dict(CONFIGS[args.config])
-    if args.sampler:
-        cfg["sampler"] = "counter" if args.sampler == "counter" else "resident"
+    ap.add_argument("--background-prep", type=int, choices=(0, 1, 2), default=1,
+                    help="the headline's background mode: 1 (default) = Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) on every "
+                         "background like the reference (DataGenerator.cpp:1186-1192); 0 = centre crops; 2 = one resampling")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the pass with the other background mode (centre_crop_backgrounds)")
+    ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1 (what --gpus N > 1 does by itself)")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="launcher check: every rank prints its rank environment as one JSON line and exits (no torch, no GPU)")
+    return ap.parse_args(argv)
 
+
+# ---- the launcher: `python3 bench.py --gpus N` starts its own ranks ----------------------------------------------------
+def launch(args, argv):
+    """Parent of an N-rank run.  It must not touch the GPU (no torch.cuda, no libofdg, no HIP call): the children are
+    started before anything in this process could initialise it, one per GPU, with the rendezvous in their environment;
+    rank 0's stdout (the ONE JSON line) is relayed, everybody's stderr passes through, and the exit code is non-zero if
+    any rank's is.  A rank that dies takes the others down (they would wait for it in a collective)."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    child_argv = [a for a in argv if a != "--launcher"]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OFDG_BENCH_LAUNCHED="1")
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")       # the timing barrier runs over gloo on the loopback interface
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 or args.launch_only else subprocess.DEVNULL, text=True))
+    rc = 0
+    alive = set(range(n))
+    deadline = None
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py launcher: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                deadline = time.time() + 20.0  # (they normally fail by themselves: the start-up is decided collectively)
+        if rc != 0 and alive and time.time() > deadline:
+            for r in alive:
+                procs[r].send_signal(signal.SIGTERM)  # exactly the PIDs started above
+            time.sleep(2.0)
+            for r in alive:
+                if procs[r].poll() is None:
+                    procs[r].kill()
+            deadline = time.time() + 60.0
+        time.sleep(0.02)
+    outs = [p.stdout.read() if p.stdout else "" for p in procs]
+    if args.launch_only:
+        ranks = []
+        for o in outs:
+            ranks += [json.loads(l) for l in o.splitlines() if l.strip().startswith("{")]
+        print(json.dumps({"launcher": "bench.py", "n_gpus": n, "master_port": port, "ranks": sorted(ranks, key=lambda d: d["rank"])}))
+    else:
+        sys.stdout.write(outs[0])
+    sys.stdout.flush()
+    return rc
+
+
+class Plumbing:
+    """What bench.py needs from torch.distributed around the native path: a barrier, the max over ranks of the timing and
+    the gather of the proof fields - on CPU tensors (gloo over the loopback interface), so that the only RCCL communicator
+    of the process is the library's own (csrc/comm.cpp).  If the gloo side cannot be used the same calls run on device
+    tensors (torch's NCCL = RCCL) instead; `self.how` says which."""
+
+    def __init__(self, world):
+        self.world = world
+        self.how = "single process"
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group()  # default backends: gloo for CPU tensors, nccl (RCCL) for device tensors, the latter made on first use
+            self.dist = dist
+            self.device = "cpu"
+            try:
+                self._reduce([1.0], "max")
+                self.how = "torch.distributed over gloo (CPU tensors)"
+            except Exception as e:  # noqa: BLE001
+                self.device = "cuda"
+                self.how = "torch.distributed over nccl (gloo unusable: %s)" % str(e)[:120]
+
+    def _reduce(self, values, op):
+        import torch
+        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN)
+        return [float(v) for v in t.tolist()]
+
+    def reduce(self, value, op="max"):
+        return value if self.world == 1 else self._reduce([value], op)[0]
+
+    def barrier(self):
+        import torch
+        if self.world > 1:
+            self._reduce([0.0], "max")
+        if torch.cuda.is_available():  # (the CPU test of this class has no device)
+            torch.cuda.synchronize()
+
+    def gather_ints(self, mine):
+        import torch
+        if self.world == 1:
+            return [list(mine)]
+        t = torch.tensor(mine, dtype=torch.int64, device=self.device)
+        out = [t.clone() for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[int(v) for v in o.tolist()] for o in out]
+
+    def store(self):
+        return self.dist.distributed_c10d._get_default_store()
+
+    def close(self):
+        if self.world > 1:
+            self._reduce([0.0], "max")
+            self.dist.destroy_process_group()
+
+
+def make_generator(ofdg, cfg, prm, pl, rank, world, local_rank, allow_fallback, background_prep):
+    """The context + texture pool of this rank.  world > 1: the one collective of this path, native - rank 0's seed /
+    stream / pool header + texture index table in ONE ncclBroadcast on the library's own RCCL communicator (the unique id
+    travels through the launcher's store).  Success or failure is decided by all ranks together: a root that cannot set
+    itself up broadcasts a failure status (bcast_abort) instead of leaving the others in the collective, and after the
+    broadcast the ranks agree (ofdg_comm_agree) that every one of them built its context and pool."""
+    if world == 1:
+        gen = ofdg.Generator(prm)
+        gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+        return gen, prm, "single process", None
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)  # one process per GPU: the device is bound before any HIP work
-    ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
-
-    counter = cfg["sampler"] == "counter"
-    W, H, BATCH = cfg["W"], cfg["H"], cfg["batch"]
-    prm = ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH,
-                              rank=rank, world_size=world, device=local_rank, sampler=1 if counter else 0, seed=SEED,
-                              background_prep=1 if args.background_prep else 0)
-    startup = "single process"
-    gen = None
-    rccl_ranks = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")  # (barriers, the gathers of the proof fields and the max over ranks of the timing)
-        # the one collective of this path, native: rank 0's seed / stream / pool header + texture index table in ONE
-        # ncclBroadcast on the library's own RCCL communicator (the unique id travels through the launcher's store).
-        # Success or failure is decided by all ranks together: a root that cannot set itself up broadcasts a failure
-        # status (bcast_abort) instead of leaving the others in the collective.
-        err = None
-        try:
-            comm = ofdg.Comm.from_store(dist.distributed_c10d._get_default_store(), rank, world, local_rank)
-            rccl_ranks = comm.nccl_count()
-            if rank == 0:
-                try:
-                    gen = ofdg.Generator(prm)
-                    gen.pool_synthetic(*cfg["pool"], POOL_SEED)
-                except Exception:
-                    comm.bcast_abort()
-                    raise
-            setup, table = comm.bcast_setup(gen)
+    err, gen, rccl_ranks, startup, comm = None, None, None, None, None
+    try:
+        comm = ofdg.Comm.from_store(pl.store(), rank, world, local_rank)
+        if rank == 0:
+            try:  # EVERYTHING the root does before the broadcast: whatever fails, the receivers are told
+                rccl_ranks = comm.nccl_count()
+                gen = ofdg.Generator(prm)
+                gen.pool_synthetic(*cfg["pool"], POOL_SEED)
+            except Exception:
+                comm.bcast_abort()
+                raise
+        setup, table = comm.bcast_setup(gen)
+        local = None
+        try:  # alone again: the others must not be left in the next collective if this fails
             if rank != 0:
+                rccl_ranks = comm.nccl_count()
                 prm = comm.params_of(setup)
                 gen = ofdg.Generator(prm)
                 gen.pool_from_setup(setup, table)
+        except Exception as e:  # noqa: BLE001
+            local = e
+        comm.agree(local is None)
+        if local is not None:
+            raise local
+        startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
+    except Exception as e:  # noqa: BLE001
+        err = e
+    finally:
+        if comm is not None:
             comm.close()
-            startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
-        except Exception as e:
-            err = e
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # (every rank gets here: nobody waits in a broadcast the root never entered)
-        if int(ok.item()) != 1:
-            if not args.allow_fallback:
-                sys.stderr.write("rank %d: native multi-GPU start-up failed%s\n" % (rank, ": %s" % err if err else " on another rank"))
-                dist.destroy_process_group()
-                raise SystemExit(3)
-            header = torch.tensor([cfg["mode"], W, H, cfg["nobj"], *cfg["pool"], POOL_SEED, SEED], dtype=torch.int64, device="cuda")
-            if rank != 0:
-                header.zero_()
-            dist.broadcast(header, src=0)
-            mode, W, H, nobj, pn, pw, ph, pseed, seed = [int(v) for v in header.tolist()]
-            prm = ofdg.default_params(width=W, height=H, mode=mode, num_objects=nobj, batch_size=BATCH, rank=rank, world_size=world,
-                                      device=local_rank, sampler=1 if counter else 0, seed=seed,
-                                      background_prep=1 if args.background_prep else 0)
-            gen = ofdg.Generator(prm)
-            gen.pool_synthetic(pn, pw, ph, pseed)
-            rccl_ranks = None
-            startup = "FALLBACK: torch.distributed broadcast (--allow-fallback; the native start-up failed: %s)" % str(err)[:200]
-    else:
+    ok = pl.reduce(0.0 if err else 1.0, "min")  # (every rank gets here: nobody waits in a broadcast the root never entered)
+    if ok != 1.0:
+        if not allow_fallback:
+            sys.stderr.write("rank %d: native multi-GPU start-up failed%s\n" % (rank, ": %s" % err if err else " on another rank"))
+            pl.close()
+            raise SystemExit(3)
+        import torch.distributed as dist
+        W, H = cfg["W"], cfg["H"]
+        header = torch.tensor([cfg["mode"], W, H, cfg["nobj"], *cfg["pool"], POOL_SEED, SEED], dtype=torch.int64, device=pl.device)
+        if rank != 0:
+            header.zero_()
+        dist.broadcast(header, src=0)
+        mode, W, H, nobj, pn, pw, ph, pseed, seed = [int(v) for v in header.tolist()]
+        prm = ofdg.default_params(width=W, height=H, mode=mode, num_objects=nobj, batch_size=cfg["batch"], rank=rank, world_size=world,
+                                  device=local_rank, sampler=prm.sampler, seed=seed, background_prep=background_prep)
         gen = ofdg.Generator(prm)
-        gen.pool_synthetic(*cfg["pool"], POOL_SEED)
-    if cfg["mode"] == 9:
-        gen.warp_generate(2, SEED)  # seeded displacer lists: every rank generates the same fields
-    stream = torch.cuda.current_stream().cuda_stream
-    NBUF = 2 * gen.num_chains()
-    outs = [ofdg.alloc_outputs(BATCH, H, W) for _ in range(NBUF)]
+        gen.pool_synthetic(pn, pw, ph, pseed)
+        rccl_ranks = None
+        startup = "FALLBACK: torch.distributed broadcast (--allow-fallback; the native start-up failed: %s)" % str(err)[:200]
+    return gen, prm, startup, rccl_ranks
 
+
+def timed_pass(ofdg, gen, cfg, pl, outs, steps, warmup, rank, world, stream):
+    """W untimed warm-up steps, then exactly K steps between barrier + device-wide synchronisation on both sides; the max
+    over ranks of the time.  Returns (seconds, step function, host sampler rate)."""
+    import torch
+    BATCH, NBUF = cfg["batch"], len(outs)
     host_sampler_rate = None
-    if counter:
-        def step(i):
-            gen.forward(*outs[i % NBUF], gen.next_stream())  # samples (step*world + rank)*B + [0, B) on the device, then renders
-    elif cfg["sampler"] == "ref":
-        def step(i):  # config 1: the reference-stream sampler on the host inside the step, like load_batch
-            gen.forward(*outs[i % NBUF], gen.next_stream())
+    if cfg["sampler"] in ("counter", "ref"):
+        def step(i):  # counter: samples (step*world + rank)*B + [0, B) on the device, then renders; ref (config 1): the
+            gen.forward(*outs[i % NBUF], gen.next_stream())  # reference-stream sampler on the host inside the step, like load_batch
     else:
         # every rank walks the same reference stream and keeps its own block of each B*world tasks
-        sampler = ofdg.HostSampler(cfg["mode"], W, H, cfg["nobj"])
+        sampler = ofdg.HostSampler(cfg["mode"], cfg["W"], cfg["H"], cfg["nobj"])
         t_s = time.perf_counter()
         for slot in range(NSLOT):
             tasks, bps, n_bps = sampler.next(BATCH * world, cap=BATCH * world * 64)
@@ -232,39 +345,67 @@ def main():
         def step(i):
             gen.render_slot(i % NSLOT, *outs[i % NBUF], gen.next_stream())
     gen.synchronize(stream)
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     gen.synchronize(stream)
     gen.set_profiling(1)  # HIP events around the compose kernel, on the launch stream
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
+    pl.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    barrier()
+    pl.barrier()
     gen.synchronize(stream)  # raises if a kernel flagged a capacity error
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    return pl.reduce(dt, "max"), step, host_sampler_rate
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    launched = "WORLD_SIZE" in os.environ
+    if args.launch_only and launched:
+        if os.environ.get("OFDG_BENCH_TEST_FAIL_RANK") == os.environ["RANK"]:  # (the launcher's test: a rank that dies)
+            return 5
+        print(json.dumps({k.lower(): (int(os.environ[k]) if os.environ[k].isdigit() else os.environ[k])
+                          for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        return 0
+    if not launched and (args.gpus > 1 or args.launcher or args.launch_only):
+        return launch(args, argv)
+    cfg = dict(CONFIGS[args.config])
+    if args.sampler:
+        cfg["sampler"] = "counter" if args.sampler == "counter" else "resident"
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python3 bench.py --gpus N` by itself, or N ranks with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)  # one process per GPU: the device is bound before any HIP work
+    ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+
+    counter = cfg["sampler"] == "counter"
+    W, H, BATCH = cfg["W"], cfg["H"], cfg["batch"]
+    bgp = args.background_prep
+
+    def params(background_prep):
+        return ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH, rank=rank,
+                                   world_size=world, device=local_rank, sampler=1 if counter else 0, seed=SEED,
+                                   background_prep=background_prep)
+
+    pl = Plumbing(world)
+    gen, prm, startup, rccl_ranks = make_generator(ofdg, cfg, params(bgp), pl, rank, world, local_rank, args.allow_fallback, bgp)
+    if cfg["mode"] == 9:
+        gen.warp_generate(2, SEED)  # seeded displacer lists: every rank generates the same fields
+    stream = torch.cuda.current_stream().cuda_stream
+    NBUF = 2 * gen.num_chains()
+    outs = [ofdg.alloc_outputs(BATCH, H, W) for _ in range(NBUF)]
+
+    dt, step, host_sampler_rate = timed_pass(ofdg, gen, cfg, pl, outs, args.steps, args.warmup, rank, world, stream)
 
     # every rank's first global sample index of steps 0 and 1 (the sharding rule the library applies, gathered)
-    mine = torch.tensor([ofdg.shard_first_index(k, BATCH, world, rank) for k in (0, 1)], dtype=torch.int64, device="cuda")
-    shards = [mine.clone() for _ in range(world)]
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_gather(shards, mine)
-    shards = [[int(v) for v in t.tolist()] for t in shards]
+    shards = pl.gather_ints([ofdg.shard_first_index(k, BATCH, world, rank) for k in (0, 1)])
 
     compose_ms = gen.kernel_ms("compose")
     parts = alone = cpu_base = None
@@ -284,48 +425,33 @@ def main():
         alone = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
         gen.set_profiling(0)
         if world == 1 and not args.no_cpu_baseline:
-            cpu_base = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool)
+            cpu_base = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool, background_prep=1 if bgp else 0)
     ctx_info, n_chains = gen.info(), gen.num_chains()
-    # The headline context is closed before the reference-equivalent one is made: two contexts would own ten streams on the
+    # The headline context is closed before the secondary one is made: two contexts would own ten streams on the
     # process's eight hardware queues, and chains that share a queue run one after the other.
     gen.synchronize(stream)
     gen.close()
     del gen
 
-    # the reference-equivalent pass: the same workload with Texture::getRandomizedCrop on every background
-    ref_eq = None
-    if not args.no_reference_equivalent and not args.background_prep and counter:
-        prm2 = ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH, rank=rank,
-                                   world_size=world, device=local_rank, sampler=1, seed=SEED, background_prep=1)
-        gen2 = ofdg.Generator(prm2)
+    # the secondary pass: the same workload with the other background mode (headline 1 or 2 -> centre crops; 0 -> mode 1)
+    secondary = None
+    bgp2 = 0 if bgp else 1
+    if not args.no_secondary and counter:
+        gen2 = ofdg.Generator(params(bgp2))
         gen2.pool_synthetic(*cfg["pool"], POOL_SEED)
         if cfg["mode"] == 9:
             gen2.warp_generate(2, SEED)
         steps2 = min(args.steps, 1000)
-        for i in range(args.warmup):
-            gen2.forward(*outs[i % NBUF], gen2.next_stream())
-        gen2.synchronize(stream)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps2):
-            gen2.forward(*outs[i % NBUF], gen2.next_stream())
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        barrier()
-        gen2.synchronize(stream)
-        t2 = torch.tensor([dt2], dtype=torch.float64, device="cuda")
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        dt2 = float(t2.item())
+        dt2, _, _ = timed_pass(ofdg, gen2, cfg, pl, outs, steps2, args.warmup, rank, world, stream)
         v2 = steps2 * BATCH * world / dt2
-        ref_eq = {"value": v2, "unit": "samples/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
-                  "whole_step_frac": v2 / world * 38 * W * H / 1e9 / HBM_PEAK_GBS, "background_prep": 1,
-                  "note": "background_prep = 1: getRandomizedCrop(2W, 2H, rot, zoom, shift) per sample (DataGenerator.cpp:1186-1192), "
-                          "the CImg chain stage by stage on the device; same algorithmic bytes as the headline (the prepared "
-                          "textures are extra traffic)"}
-        if world == 1 and not args.no_cpu_baseline:
-            ref_eq["cpu_baseline"] = cpu_baseline(ofdg, gen2, cfg, budget_s=12.0, host_pool=args.cpu_pool, background_prep=1)
+        secondary = {"value": v2, "unit": "samples/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
+                     "whole_step_frac": v2 / world * 38 * W * H / 1e9 / HBM_PEAK_GBS, "background_prep": bgp2,
+                     "note": ("background_prep = 0: every background is the centre 2W x 2H crop of its pool image (no rotation / zoom / shift "
+                              "of the texture: less work than the reference does per sample; the headline of rounds 1-3)") if bgp2 == 0 else
+                             ("background_prep = 1: getRandomizedCrop(2W, 2H, rot, zoom, shift) per sample (DataGenerator.cpp:1186-1192), "
+                              "the CImg chain stage by stage on the device")}
+        if bgp2 == 1 and world == 1 and not args.no_cpu_baseline:
+            secondary["cpu_baseline"] = cpu_baseline(ofdg, gen2, cfg, budget_s=12.0, host_pool=args.cpu_pool, background_prep=1)
         gen2.close()
         del gen2
 
@@ -341,16 +467,21 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            ent = tj.get("config%d" % args.config)
-            if ent and ent.get("kernel") == kernel and not args.background_prep:
+            ent = tj.get("config%d_background_prep_%d" % (args.config, bgp))
+            if ent and ent.get("kernel") == kernel and ent.get("background_prep", 0) == bgp:
                 traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         out = {
             "metric": "training samples/sec (img0+img1+flow, %dx%d)" % (W, H),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
-            "config": {"workload": cfg["name"], "baseline_config": args.config, "batch_per_gpu": BATCH,
-                       "background_prep": bool(args.background_prep), "startup": startup, "rccl_ranks": rccl_ranks,
+            "config": {"workload": cfg["name"] + (
+                           "; backgrounds prepared per sample like the reference: getRandomizedCrop(2W, 2H, rot, zoom, shift) (background_prep = 1)" if bgp == 1 else
+                           "; CENTRE-CROP backgrounds (background_prep = 0: lighter than the reference's per-sample getRandomizedCrop)" if bgp == 0 else
+                           "; backgrounds prepared by one resampling (background_prep = 2)"),
+                       "baseline_config": args.config, "batch_per_gpu": BATCH,
+                       "background_prep": bgp, "startup": startup, "rccl_ranks": rccl_ranks, "plumbing": pl.how,
+                       "launched_by": "bench.py launcher" if os.environ.get("OFDG_BENCH_LAUNCHED") else ("torch.distributed.run / caller" if launched else "direct"),
                        "shards": {"first_index_of_steps_0_and_1_by_rank": shards}, "context": ctx_info, "output_buffer_sets": NBUF,
                        "chains": n_chains, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
@@ -376,17 +507,15 @@ def main():
             "kernel_ms": parts, "kernel_ms_alone": alone,
             "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
-        out["reference_equivalent"] = ref_eq
+        out["centre_crop_backgrounds" if bgp2 == 0 else "reference_equivalent"] = secondary
         if host_sampler_rate is not None:
             out["host_ref_sampler_samples_per_s"] = host_sampler_rate
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    pl.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,6 +34,7 @@ extern "C" {
 #define OFDG_EHIP       (-4) /* HIP runtime failure / extension missing  */
 #define OFDG_ECAPACITY  (-5) /* fixed-capacity array exceeded            */
 #define OFDG_EINVAL     (-6) /* invalid argument                         */
+#define OFDG_ESTARTUP   (-7) /* multi-GPU start-up: another rank failed  */
 
 /* ObjType_t (DGH:369-374) and PolySegmentType_t (DGH:377-381) values. */
 #define OFDG_OBJ_DUMMY     0
@@ -404,6 +405,12 @@ int ofdg_comm_nccl_count(ofdg_comm* comm);
  * checks that all of its buffers exist and the ranks agree on that (one ncclAllReduce of a flag) before the first
  * payload broadcast: a rank that cannot take part makes the call fail on every rank. */
 int ofdg_comm_bcast_pool(ofdg_comm* comm, int root, ofdg_ctx* ctx);
+/* "Did every rank get this far?"  One ncclAllReduce(min) of a flag; every rank of the communicator must call it, with
+ * local_ok = 0 if its own step failed (context creation, pool allocation ...).  Returns OFDG_OK on every rank if all
+ * passed 1, otherwise OFDG_ESTARTUP on every rank - so a rank that failed between two collectives takes the others
+ * out with it instead of leaving them waiting in the next one.  (A failure of the collective itself returns OFDG_EHIP
+ * on the rank that saw it; RCCL then aborts the others.) */
+int ofdg_comm_agree(ofdg_comm* comm, int local_ok);
 /* The header / index table of a context's stream and pool (what the root broadcasts), and the parameters a
  * receiving rank creates its context with (rank, world_size and device come from the communicator). */
 int ofdg_setup_of(const ofdg_ctx* ctx, ofdg_setup* setup, ofdg_tex_entry* table, int table_cap);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFDG_LIB") or os.path.join(HERE, "lib", "libofdg.so")  # OFDG_LIB: A/B-test another build
 MAX_SEG = 20
 
-OK, EBADMODE, ETEXTURES, EOBJTYPE, EHIP, ECAPACITY, EINVAL = 0, -1, -2, -3, -4, -5, -6
+OK, EBADMODE, ETEXTURES, EOBJTYPE, EHIP, ECAPACITY, EINVAL, ESTARTUP = 0, -1, -2, -3, -4, -5, -6, -7
 OBJ_ELLIPSE, OBJ_POLYGON, OBJ_COMPOSITE = 1, 2, 3
 SEG_DUMMY, SEG_LINE, SEG_CURVE3 = 0, 1, 3
 
@@ -96,7 +96,7 @@ EXPORTS = [
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
     "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_num_chains",
     "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
-    "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_abort", "ofdg_comm_nccl_count", "ofdg_comm_bcast_pool", "ofdg_setup_of", "ofdg_setup_params",
+    "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_abort", "ofdg_comm_nccl_count", "ofdg_comm_bcast_pool", "ofdg_comm_agree", "ofdg_setup_of", "ofdg_setup_params",
     "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_pool_device_image", "ofdg_layer_create_dist",
 ]
 
@@ -191,6 +191,7 @@ def lib():
         L.ofdg_comm_last_error.restype = C.c_char_p
         L.ofdg_comm_bcast_setup.argtypes = [vp, i32, C.POINTER(Setup), vp, i32]
         L.ofdg_comm_bcast_pool.argtypes = [vp, i32, vp]
+        L.ofdg_comm_agree.argtypes = [vp, i32]
         L.ofdg_comm_bcast_abort.argtypes = [vp, i32, i32, i32]
         L.ofdg_comm_nccl_count.argtypes = [vp]
         L.ofdg_setup_of.argtypes = [vp, C.POINTER(Setup), vp, i32]
@@ -564,6 +565,11 @@ class Comm:
 
     def bcast_pool(self, gen, root=0):
         self._check(lib().ofdg_comm_bcast_pool(self.h, root, gen.h))
+
+    def agree(self, local_ok=True):
+        """Every rank calls it after a step it did alone (context, pool ...), with local_ok = False if that step
+        failed: raises ESTARTUP on EVERY rank unless all passed True - nobody is left in the next collective."""
+        self._check(lib().ofdg_comm_agree(self.h, 1 if local_ok else 0))
 
     def close(self):
         if getattr(self, "h", None):

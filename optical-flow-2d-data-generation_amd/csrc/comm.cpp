@@ -74,6 +74,7 @@ struct ofdg_comm {
   hipStream_t stream = nullptr;
   void* d_buf = nullptr;
   size_t d_bytes = 0;
+  int* d_flag = nullptr;  // comm_agree
   std::string err;
 };
 
@@ -114,6 +115,12 @@ int ofdg_comm_unique_id(void* id) {
 static int comm_finish(std::unique_ptr<ofdg_comm>& c, ofdg_comm** out) {
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { g_comm_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); return OFDG_EHIP; }
+  // the word the ranks agree through (ofdg_comm_agree): allocated here, so that agreeing cannot fail on an allocation
+  if ((e = hipMalloc((void**)&c->d_flag, 256)) != hipSuccess || (e = hipMemset(c->d_flag, 0, 256)) != hipSuccess) {
+    g_comm_error = std::string("hipMalloc (agreement flag): ") + hipGetErrorString(e);
+    (void)hipStreamDestroy(c->stream);
+    return OFDG_EHIP;
+  }
   *out = c.release();
   return OFDG_OK;
 }
@@ -150,6 +157,7 @@ void ofdg_comm_destroy(ofdg_comm* c) {
   if (!c) return;
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->d_buf) (void)hipFree(c->d_buf);
+  if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->owned && c->comm) { Rccl* R = rccl(nullptr); if (R) (void)R->CommDestroy(c->comm); }
   delete c;
 }
@@ -229,19 +237,19 @@ int ofdg_comm_nccl_count(ofdg_comm* c) {
 }
 
 // do all ranks say `ok`?  (one ncclAllReduce(min) of a flag)
+// The flag's device word is allocated when the communicator is made (comm_finish), so that nothing between "this rank
+// decides its flag" and "this rank enters the all-reduce" can fail locally and leave the other ranks in the collective.
 static int comm_agree(ofdg_comm* c, Rccl* R, bool ok, bool* all_ok) {
-  const size_t need = sizeof(int);
-  if (c->d_bytes < need) {
-    if (c->d_buf) COMM_HIP(c, hipFree(c->d_buf));
-    c->d_buf = nullptr;
-    COMM_HIP(c, hipMalloc(&c->d_buf, 256));
-    c->d_bytes = 256;
-  }
   int flag = ok ? 1 : 0;
-  COMM_HIP(c, hipMemcpyAsync(c->d_buf, &flag, sizeof(int), hipMemcpyHostToDevice, c->stream));
-  COMM_NCCL(c, R, R->AllReduce(c->d_buf, c->d_buf, 1, ncclInt32, ncclMin, c->comm, c->stream));
-  COMM_HIP(c, hipMemcpyAsync(&flag, c->d_buf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  *all_ok = false;
+  // (a failed copy of the flag is a local failure like any other: say "not ok" with whatever the word holds - it is
+  //  zeroed at allocation and after every agreement - and still enter the collective)
+  hipError_t e_in = hipMemcpyAsync(c->d_flag, &flag, sizeof(int), hipMemcpyHostToDevice, c->stream);
+  COMM_NCCL(c, R, R->AllReduce(c->d_flag, c->d_flag, 1, ncclInt32, ncclMin, c->comm, c->stream));
+  COMM_HIP(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  COMM_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   COMM_HIP(c, hipStreamSynchronize(c->stream));
+  if (e_in != hipSuccess) { c->err = std::string("hipMemcpyAsync (agreement flag): ") + hipGetErrorString(e_in); return OFDG_EHIP; }
   *all_ok = flag == 1;
   return OFDG_OK;
 }
@@ -271,7 +279,7 @@ int ofdg_comm_bcast_pool(ofdg_comm* c, int root, ofdg_ctx* ctx) {
       else images.emplace_back(ip, ib);
     }
   }
-  COMM_HIP(c, hipSetDevice(c->device));
+  if (hipSetDevice(c->device) != hipSuccess && rc == OFDG_OK) { c->err = "hipSetDevice failed"; rc = OFDG_EHIP; }  // (no early return in front of the agreement)
   // ... and the ranks agree that everybody can: a rank that returned early would leave the others in ncclBroadcast
   bool all_ok = false;
   { int rca = comm_agree(c, R, rc == OFDG_OK, &all_ok); if (rca != OFDG_OK) return rca; }
@@ -283,6 +291,20 @@ int ofdg_comm_bcast_pool(ofdg_comm* c, int root, ofdg_ctx* ctx) {
   if (ptr2) COMM_NCCL(c, R, R->Broadcast(ptr2, ptr2, (size_t)bytes2, ncclUint8, root, c->comm, c->stream));
   for (const auto& im : images) COMM_NCCL(c, R, R->Broadcast(im.first, im.first, (size_t)im.second, ncclUint8, root, c->comm, c->stream));
   COMM_HIP(c, hipStreamSynchronize(c->stream));
+  return OFDG_OK;
+}
+
+int ofdg_comm_agree(ofdg_comm* c, int local_ok) {
+  if (!c) return OFDG_EINVAL;
+  Rccl* R = rccl(&c->err);
+  if (!R) return OFDG_EHIP;
+  bool all_ok = false;
+  const int rc = comm_agree(c, R, local_ok != 0, &all_ok);
+  if (rc != OFDG_OK) return rc;
+  if (!all_ok) {
+    c->err = local_ok ? "multi-GPU start-up: another rank failed (see its message)" : "multi-GPU start-up: this rank failed";
+    return OFDG_ESTARTUP;
+  }
   return OFDG_OK;
 }
 

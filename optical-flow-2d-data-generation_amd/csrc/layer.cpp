@@ -5,6 +5,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -263,6 +264,7 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg
   ofdg_setup su;
   std::memset(&su, 0, sizeof(su));
   const int rank = comm ? ofdg_comm_rank(comm) : 0;
+  std::exception_ptr local_failure;
   auto create = [&]() {
     int rc = ofdg_create(&cfg_.params, &ctx_);
     if (rc == OFDG_EBADMODE) throw std::runtime_error("BAD MODE");  // DataGenerator.cpp:2004
@@ -296,14 +298,25 @@ DataGenerationLayer::DataGenerationLayer(const std::string& layer_prototxt, ofdg
       }
     } else {
       bcast();
-      ofdg_params p;
-      ofdg_setup_params(&su, comm, &p);
-      p.prefetch = cfg_.params.prefetch;
-      p.first_level_threads = cfg_.params.first_level_threads; p.second_level_threads = cfg_.params.second_level_threads;
-      cfg_.params = p;
-      create();
-      if (ofdg_setup_alloc_pool(ctx_, &su, table.data()) != OFDG_OK)
-        throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx_));
+      // From here to the next collective this rank works alone (context, pool allocation): if that fails the others
+      // must not be left waiting in the collective - the failure is kept and every rank learns of it in the agreement.
+      try {
+        ofdg_params p;
+        ofdg_setup_params(&su, comm, &p);
+        p.prefetch = cfg_.params.prefetch;
+        p.first_level_threads = cfg_.params.first_level_threads; p.second_level_threads = cfg_.params.second_level_threads;
+        cfg_.params = p;
+        create();
+        if (ofdg_setup_alloc_pool(ctx_, &su, table.data()) != OFDG_OK)
+          throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx_));
+      } catch (...) {
+        local_failure = std::current_exception();
+      }
+    }
+    if (comm) {  // every rank that came through the broadcast: did everybody set itself up?
+      const int rca = ofdg_comm_agree(comm, local_failure ? 0 : 1);
+      if (local_failure) std::rethrow_exception(local_failure);
+      if (rca != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer: ") + ofdg_comm_last_error(comm));
     }
     // a texture collection read from disk lives on rank 0 only until here: replicate it over xGMI
     if (comm && su.pool_kind != OFDG_POOL_SYNTHETIC && ofdg_comm_bcast_pool(comm, 0, ctx_) != OFDG_OK)

@@ -1,5 +1,6 @@
 """The bench line's contract (the driver parses ONE JSON line from `python bench.py ...`): run the script as the driver
-does - a child process, a few steps - and check the fields the contract names, including the reference-equivalent pass."""
+does - a child process, a few steps - and check the fields the contract names; the headline is the reference-equivalent
+workload (background_prep = 1), the centre-crop form rides along.  The same through the script's own launcher path."""
 import json
 import os
 import subprocess
@@ -10,15 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_bench_line_carries_the_contract_fields():
-    env = dict(os.environ)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+def bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", *extra],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def check_contract(d):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline"):
         assert key in d, key
@@ -34,8 +37,34 @@ def test_bench_line_carries_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == 38 * 512 * 384 * d["config"]["batch_per_gpu"]
-    # the same workload with the reference's per-sample background preparation, in the same line
-    e = d["reference_equivalent"]
-    assert e["background_prep"] == 1 and e["unit"] == "samples/s" and 0 < e["value"] < d["value"]
     # the context proves how it was set up: chains, hardware queues, shard indices of rank 0
     assert d["config"]["chains"] >= 3 and d["config"]["shards"]["first_index_of_steps_0_and_1_by_rank"] == [[0, d["config"]["batch_per_gpu"]]]
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields():
+    d = bench()
+    check_contract(d)
+    # the headline does the reference's per-sample background preparation; the lighter centre-crop form is the secondary
+    assert d["config"]["background_prep"] == 1 and "getRandomizedCrop" in d["config"]["workload"]
+    assert d["config"]["launched_by"] == "direct"
+    e = d["centre_crop_backgrounds"]
+    assert e["background_prep"] == 0 and e["unit"] == "samples/s" and e["value"] > d["value"] > 0
+    assert "reference_equivalent" not in d
+
+
+@pytest.mark.gpu
+def test_bench_line_through_the_launcher_path_has_the_same_contract():
+    """`--launcher`: the rank is a child of the script's own launcher (what `--gpus N > 1` does by itself); the relayed
+    line obeys the same contract as the direct form."""
+    d = bench("--launcher", "--no-secondary")
+    check_contract(d)
+    assert d["config"]["launched_by"] == "bench.py launcher" and d["config"]["background_prep"] == 1
+    assert d["centre_crop_backgrounds"] is None
+
+
+@pytest.mark.gpu
+def test_bench_centre_crop_headline_says_so():
+    d = bench("--background-prep", "0", "--no-secondary")
+    check_contract(d)
+    assert d["config"]["background_prep"] == 0 and "CENTRE-CROP" in d["config"]["workload"]

@@ -124,3 +124,107 @@ print(g.num_chains(), "|", g.info())
     assert n == 3 and "< 8" in info
     n, info = chains({"chains": 2, "lookahead": 1}, GPU_MAX_HW_QUEUES="8")
     assert n == 2 and "ofdg_params.chains" in info and "lookahead=1" in info
+
+
+def test_agreement_single_rank(ofdg, comm):
+    """ofdg_comm_agree: all ranks passed 1 -> OK; anybody passed 0 -> ESTARTUP on every rank (here: the one rank)."""
+    comm.agree(True)
+    with pytest.raises(ofdg.OfdgError) as e:
+        comm.agree(False)
+    assert e.value.code == ofdg.ESTARTUP
+    comm.agree(True)  # (the flag word is reset by every agreement)
+
+
+TWO_RANKS = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["OFDG_ROOT"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(rank)                      # one process per GPU, bound before any HIP work
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo")                  # rendezvous + the comparison below; the data-path start-up is native RCCL
+comm = ofdg.Comm.from_store(dist.distributed_c10d._get_default_store(), rank, world, rank)
+assert comm.nccl_count() == world
+W, H, B = 128, 96, 4
+gen = None
+rng = np.random.RandomState(11)
+imgs = [rng.randint(0, 256, (3, 200, 280)).astype(np.uint8) for _ in range(3)]
+if rank == 0:                                    # only the root holds the texture collection
+    gen = ofdg.Generator(ofdg.default_params(width=W, height=H, mode=7, num_objects=6, batch_size=B, sampler=1, seed=123, rank=0, world_size=world, device=0))
+    gen.pool_alloc(3, 280, 200)
+    for i, im in enumerate(imgs):
+        gen.pool_upload(i, im)
+su, table = comm.bcast_setup(gen)                # THE start-up collective
+if rank != 0:
+    p = comm.params_of(su)
+    assert (p.rank, p.world_size, p.device, p.seed, p.mode) == (rank, world, rank, 123, 7)
+    gen = ofdg.Generator(p)
+    gen.pool_from_setup(su, table)
+comm.agree(True)
+comm.bcast_pool(gen)                             # the pool itself, HBM -> HBM over xGMI
+assert np.array_equal(gen.pool_download_all(), np.stack(imgs)), "rank %d: the replicated pool differs" % rank
+outs = [ofdg.alloc_outputs(B, H, W) for _ in range(2)]
+for k in range(2):
+    gen.forward(*outs[k])                        # step k of THIS rank's shard
+gen.synchronize()
+# every rank re-renders every other rank's shard by global index: shards are disjoint and a pure function of the index
+for k in range(2):
+    for r in range(world):
+        first = ofdg.shard_first_index(k, B, world, r)
+        ref = ofdg.alloc_outputs(B, H, W)
+        gen.forward_counter(first, B, *ref); gen.synchronize()
+        same = all(torch.equal(a, b) for a, b in zip(ref, outs[k]))
+        assert same == (r == rank), (rank, k, r, same)
+# ... and the ranks' batches of step 0 really differ from each other (gathered on the host)
+mine = outs[0][2].cpu().reshape(-1)[:4096].contiguous()
+alls = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(alls, mine)
+assert not torch.equal(alls[0], alls[1])
+comm.close()
+dist.barrier()
+dist.destroy_process_group()
+print("TWO_RANKS_OK %d" % rank)
+'''
+
+
+def test_two_ranks_native_startup_and_sharded_forward(ofdg, tmp_path):
+    """The first box with two GPUs proves the native N > 1 path by itself: two processes (started before any GPU call),
+    ofdg_comm_bcast_setup + ofdg_comm_agree + ofdg_comm_bcast_pool over RCCL, then one sharded forward per rank."""
+    import os, socket, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL does not admit two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_ranks.py"
+    script.write_text(TWO_RANKS)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, OFDG_ROOT=root, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert "TWO_RANKS_OK 0" in outs[0][0] and "TWO_RANKS_OK 1" in outs[1][0]
+
+
+def test_bench_two_gpus_starts_by_itself(ofdg):
+    """`python3 bench.py --gpus 2` as the driver would start it (no torch.distributed.run): skipped on a one-GPU box."""
+    import json, os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["launched_by"] == "bench.py launcher"
+    B = d["config"]["batch_per_gpu"]
+    assert d["config"]["shards"]["first_index_of_steps_0_and_1_by_rank"] == [[0, 2 * B], [B, 3 * B]]

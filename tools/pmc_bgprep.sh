@@ -9,7 +9,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 5 200 rocprofv3 --pmc $line --output-format csv -d $out/p$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --background-prep --no-cpu-baseline --steps 40 --warmup 10 > $out/p$i.log 2>&1
+  timeout -k 5 200 rocprofv3 --pmc $line --output-format csv -d $out/p$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --background-prep 1 --no-cpu-baseline --steps 40 --warmup 10 > $out/p$i.log 2>&1
   python3 $GRAFT_REPO_ROOT/tools/pmcstats.py $out/p$i bgprep >> $out/summary.txt 2>> $out/err.txt
   rm -rf $out/p$i
 done <<'PASSES'

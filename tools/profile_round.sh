@@ -14,15 +14,15 @@ echo "[bench] driver-like"; timeout -k 10 300 python3 bench.py --gpus 1 --steps 
 for cfg in 1 3 4 5; do
   echo "[bench] config $cfg"; timeout -k 10 400 python3 bench.py --config $cfg > $out/bench_line_config$cfg.json 2>> $out/bench_stderr.txt
 done
-echo "[bench] background_prep"; timeout -k 10 300 python3 bench.py --background-prep --no-cpu-baseline > $out/bench_line_config2_background_prep.json 2>> $out/bench_stderr.txt
-echo "[bench] resident"; timeout -k 10 300 python3 bench.py --sampler resident --no-cpu-baseline --no-reference-equivalent > $out/bench_line_config2_resident.json 2>> $out/bench_stderr.txt
+echo "[bench] background_prep"; timeout -k 10 300 python3 bench.py --background-prep 1 --no-cpu-baseline > $out/bench_line_config2_background_prep.json 2>> $out/bench_stderr.txt
+echo "[bench] resident"; timeout -k 10 300 python3 bench.py --sampler resident --no-cpu-baseline --no-secondary > $out/bench_line_config2_resident.json 2>> $out/bench_stderr.txt
 cd /tmp && export TMPDIR=/tmp
 echo "[rocprofv3] kernel trace"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-reference-equivalent > $out/bench_line_under_rocprof.json 2>/dev/null
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary > $out/bench_line_under_rocprof.json 2>/dev/null
 for cfg in 2 3; do
   echo "[rocprofv3] pmc config $cfg"
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-reference-equivalent --steps 60 > /dev/null 2>&1
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-reference-equivalent --steps 60 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-secondary --steps 60 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c$cfg -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --no-cpu-baseline --no-secondary --steps 60 > /dev/null 2>&1
 done
 cd "$GRAFT_REPO_ROOT"
 python3 tools/kstats.py $out/trace > $out/kernel_stats.txt

@@ -142,6 +142,7 @@ def parse_args(argv=None):
                     help="the headline's background mode: 1 (default) = Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift) on every "
                          "background like the reference (DataGenerator.cpp:1186-1192); 0 = centre crops; 2 = one resampling")
     ap.add_argument("--no-secondary", action="store_true", help="skip the pass with the other background mode (centre_crop_backgrounds)")
+    ap.add_argument("--chains", type=int, default=0, help="ofdg_params.chains (0: the context's own choice; 1: every kernel of a step runs alone, one step after the other)")
     ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1 (what --gpus N > 1 does by itself)")
     ap.add_argument("--launch-only", action="store_true",
                     help="launcher check: every rank prints its rank environment as one JSON line and exits (no torch, no GPU)")
@@ -392,7 +393,7 @@ def main():
     def params(background_prep):
         return ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=BATCH, rank=rank,
                                    world_size=world, device=local_rank, sampler=1 if counter else 0, seed=SEED,
-                                   background_prep=background_prep)
+                                   background_prep=background_prep, chains=args.chains)
 
     pl = Plumbing(world)
     gen, prm, startup, rccl_ranks = make_generator(ofdg, cfg, params(bgp), pl, rank, world, local_rank, args.allow_fallback, bgp)

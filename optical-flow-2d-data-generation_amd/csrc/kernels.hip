@@ -1729,14 +1729,19 @@ struct RotPair { f32x2 mx, my; };
 __device__ __forceinline__ RotPair bgprep_rot_coords(const DevBgPrep& p, float xc0, float xc1, float yc) {
   const f32x2 xc = {xc0, xc1};
   RotPair r;
-  r.mx = (f32x2{p.w2, p.w2} + xc * f32x2{p.ca, p.ca}) + f32x2{__fmul_rn(yc, p.sa), __fmul_rn(yc, p.sa)};
-  r.my = (f32x2{p.h2, p.h2} - xc * f32x2{p.sa, p.sa}) + f32x2{__fmul_rn(yc, p.ca), __fmul_rn(yc, p.ca)};
+  // (w2, h2 as opaque scalars: read straight into the vector initialisers the two loads become vector loads of the record,
+  //  which keep a copy of the record's floats in private memory - scratch traffic in the middle of the callers' loops)
+  float w2 = p.w2, h2 = p.h2;
+  asm("" : "+v"(w2), "+v"(h2));
+  r.mx = (f32x2{w2, w2} + xc * f32x2{p.ca, p.ca}) + f32x2{__fmul_rn(yc, p.sa), __fmul_rn(yc, p.sa)};
+  r.my = (f32x2{h2, h2} - xc * f32x2{p.sa, p.sa}) + f32x2{__fmul_rn(yc, p.ca), __fmul_rn(yc, p.ca)};
   return r;
 }
 __device__ __forceinline__ bool bgprep_shift_plain(const DevBgPrep& p) { return p.shx >= 0 && p.shx <= p.pw && p.shy >= 0 && p.shy <= p.ph; }
 // Both texels lie inside [0, pw - 1) x [0, ph - 1) of the rotated image's source coordinates (mod, mirror and the Neumann
 // clamp are identities, x + 1 and y + 1 exist) and the shift is plain (0 <= shift <= size).
-__device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const RotPair& r, bool second) {
+template <class PairFn>
+__device__ __forceinline__ uint2 bgprep_rot_inside2_t(const DevBgPrep& p, const RotPair& r, bool second, PairFn pair) {
   const f32x2 mx = r.mx, my = r.my;
   const int x0i = (int)mx.x, y0i = (int)my.x, x1i = (int)mx.y, y1i = (int)my.y;
   const f32x2 dx = mx - f32x2{(float)x0i, (float)x1i}, dy = my - f32x2{(float)y0i, (float)y1i};
@@ -1744,20 +1749,19 @@ __device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const Ro
   // the neighbour's weight is then an exact zero and the value the same.  Texel (i, j) of the shifted image = pool texel
   // (mirror(i - shx), mirror(j - shy)), for 0 <= shift <= size -k -> k - 1: x and x + 1 are neighbours in the pool too
   // (ascending, descending left of the mirror line, or twice texel 0 across it), so ONE 8-byte load per row fetches both.
-  const char* imgc = (const char*)p.image_addr;
+  // pair(row, col): pool texels (col, row) and (col + 1, row).
   auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
-  auto row_pair = [&](int xi, uint32_t ra, uint32_t rb, uint32_t* cc, uint32_t* nc, uint32_t* cn, uint32_t* nn) {
+  auto row_pair = [&](int xi, int ya, int yb, uint32_t* cc, uint32_t* nc, uint32_t* cn, uint32_t* nn) {
     const int j = xi - p.shx;
-    const uint32_t base = (uint32_t)(j >= 0 ? j : max(-j - 2, 0));
-    const uint2 r0 = gload2(imgc, (ra + base) * 4u), r1 = gload2(imgc, (rb + base) * 4u);
+    const int base = j >= 0 ? j : max(-j - 2, 0);
+    const uint2 r0 = pair(ya, base), r1 = pair(yb, base);
     const bool rev = j < 0, swap = j < -1;
     *cc = swap ? r0.y : r0.x; *nc = rev ? r0.x : r0.y;
     *cn = swap ? r1.y : r1.x; *nn = rev ? r1.x : r1.y;
   };
-  const uint32_t upw = (uint32_t)p.pw;
   uint32_t cc0, nc0, cn0, nn0, cc1 = 0, nc1 = 0, cn1 = 0, nn1 = 0;
-  row_pair(x0i, __umul24((uint32_t)sh(y0i, p.shy), upw), __umul24((uint32_t)sh(y0i + 1, p.shy), upw), &cc0, &nc0, &cn0, &nn0);
-  if (second) row_pair(x1i, __umul24((uint32_t)sh(y1i, p.shy), upw), __umul24((uint32_t)sh(y1i + 1, p.shy), upw), &cc1, &nc1, &cn1, &nn1);
+  row_pair(x0i, sh(y0i, p.shy), sh(y0i + 1, p.shy), &cc0, &nc0, &cn0, &nn0);
+  if (second) row_pair(x1i, sh(y1i, p.shy), sh(y1i + 1, p.shy), &cc1, &nc1, &cn1, &nn1);
   uint2 out = make_uint2(0, 0);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -1771,6 +1775,12 @@ __device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const Ro
     out.y |= (uint32_t)(unsigned char)val.y << b;
   }
   return out;
+}
+// ... with the taps fetched from the pool image in memory
+__device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const RotPair& r, bool second) {
+  const char* imgc = (const char*)p.image_addr;
+  const uint32_t upw = (uint32_t)p.pw;
+  return bgprep_rot_inside2_t(p, r, second, [&](int row, int col) { return gload2(imgc, (__umul24((uint32_t)row, upw) + (uint32_t)col) * 4u); });
 }
 __device__ __forceinline__ uint2 bgprep_rot_sample2(const DevBgPrep& p, float xc0, float xc1, float yc, bool second) {
   const int pw = p.pw, ph = p.ph;
@@ -1915,93 +1925,239 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
 constexpr int kFuseW = 64, kFuseH = 32;
 constexpr int kFuseCW = 90, kFuseCH = 48;  // 64 * 4/3 + 2 columns (even: texel pairs), 32 * 4/3 + 2 rows, and a margin for the +2 of the crop size
-// (six waves per SIMD: 79 VGPRs; at the five the compiler picks by itself the kernel is 2 % slower in the pipeline, at eight it spills)
-__global__ __launch_bounds__(256, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
+constexpr int kFuseWaves = 4, kFuseThreads = 64 * kFuseWaves;
+constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
+constexpr int kFuseMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
+// What one tile costs is not its arithmetic but the small dependent loads around it - which sample holds tile t, that
+// sample's record, the four resize-table entries that bound the tile's piece of C, the table entries of the tile's columns
+// and rows: measured per tile of the round-3 kernel (tools/exp_fuse_stamps.py) 11 us of "which tile is next", 6 + 5.5 us
+// in the two resize passes against 6.7 us for the rotation pass with all its gathers.  So the tile loop is a software
+// pipeline: every such load is ISSUED one pass (or one tile) before its value is needed -
+//   top        S1  sample of the next tile (prefix of the samples' tile counts: LDS), its record requested
+//              B   this tile's column / row table entries requested (used in the X and Y passes)
+//   rotation pass  C(i, j) = crop(rotate(shift(T))) sampled into LDS
+//              S2  next tile's box in B, the four table entries that bound its piece of C requested
+//   X pass         M = X-resize of C, in place
+//   Y pass         B = Y-resize of M -> memory
+//              S3  next tile's piece of C and its "inside" flag from the entries requested in S2
+struct FuseTile {
+  int s;                    // sample; n_samples: no tile left
+  int bx0, bx1, by0, by1;   // texels of B the tile renders
+  int cx0, cx1, cy0, cy1;   // texels of C it needs
+  int fits;                 // ... which fit the LDS tile of C
+  int inside;               // no mirroring / clamping anywhere in the tile: the per-texel range tests are skipped
+};
+__device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }
+__device__ __forceinline__ int fuse_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kFuseW) / kFuseW; }
+// cimg_resize_range with the two table entries it reads already in hand (e0 = at[n * s + d0], e1 = at[n * s + d1])
+__device__ __forceinline__ void fuse_range(int n, int s, int d0, int d1, int e0, int e1, int* lo, int* hi) {
+  if (s > n) { *lo = e0; *hi = min(e1 + 1, n - 1); }
+  else if (s == n) { *lo = d0; *hi = d1; }
+  else { *lo = (d0 * n) / s; *hi = ((d1 + 1) * n - 1) / s; }
+}
+// the tile's piece of C and whether the whole of it maps inside the source image (S3)
+__device__ __forceinline__ void fuse_finish_tile(const DevBgPrep& p, FuseTile& F, int TW, int TH, int ex0, int ex1, int ey0, int ey1) {
+  fuse_range(p.cw, TW, F.bx0, F.bx1, ex0, ex1, &F.cx0, &F.cx1);
+  fuse_range(p.ch, TH, F.by0, F.by1, ey0, ey1, &F.cy0, &F.cy1);
+  const int cx0 = F.cx0, cx1 = F.cx1, cy0 = F.cy0, cy1 = F.cy1;
+  F.fits = (cx1 - cx0 + 1 <= kFuseCW && cy1 - cy0 + 1 <= kFuseCH) ? 1 : 0;
+  // The usual tile: its crop coordinates need no mirroring and its four corners - so, the map being affine, all its texels
+  // (a margin of one texel covers the rounding of the per-texel evaluation) - lie inside the source image: no per-texel tests.
+  bool inside = F.fits && bgprep_shift_plain(p) && p.x0 + cx0 >= 0 && p.x0 + cx1 + 1 < p.rw && p.y0 + cy0 >= 0 && p.y0 + cy1 < p.rh;
+  if (inside) {
+    const float xa = __fsub_rn((float)(p.x0 + cx0), p.rw2), xb = __fsub_rn((float)(p.x0 + cx1 + 1), p.rw2);
+    const float ya = __fsub_rn((float)(p.y0 + cy0), p.rh2), yb = __fsub_rn((float)(p.y0 + cy1), p.rh2);
+    const RotPair ra = bgprep_rot_coords(p, xa, xb, ya), rb = bgprep_rot_coords(p, xa, xb, yb);
+    const float lo_x = fminf(fminf(ra.mx.x, ra.mx.y), fminf(rb.mx.x, rb.mx.y)), hi_x = fmaxf(fmaxf(ra.mx.x, ra.mx.y), fmaxf(rb.mx.x, rb.mx.y));
+    const float lo_y = fminf(fminf(ra.my.x, ra.my.y), fminf(rb.my.x, rb.my.y)), hi_y = fmaxf(fmaxf(ra.my.x, ra.my.y), fmaxf(rb.my.x, rb.my.y));
+    inside = lo_x >= 1.f && hi_x < (float)(p.pw - 2) && lo_y >= 1.f && hi_y < (float)(p.ph - 2);
+  }
+  F.inside = __builtin_amdgcn_readfirstlane(inside ? 1 : 0);  // (wave-uniform by construction)
+}
+// one axis of CImg's linear get_resize with the destination pixel's table entry (a0 = at[k], al = alpha[k]) already in hand:
+// cimg_resize_texel without its two loads
+template <class Texel>
+__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, Texel texel) {
+  if (sdim > n) {
+    uint32_t out = 0;
+    const double al1 = 1 - al;
+    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v1 = u32_to_double((t1 >> (8 * c)) & 255u), v2 = u32_to_double((t2 >> (8 * c)) & 255u);
+      out |= (uint32_t)(unsigned char)(al1 * v1 + al * v2) << (8 * c);
+    }
+    return out;
+  }
+  return cimg_resize_texel(n, sdim, k, (const uint16_t*)nullptr, (const double*)nullptr, texel);  // (same length / shrinking: no table)
+}
+#ifdef OFDG_FUSE_STAMPS
+// experiment builds: wall-clock ticks (10 ns) per pass, summed over the tiles of thread 0 of every workgroup; [7] = tiles
+__device__ unsigned long long g_fuse_stamps[8];
+#define FUSE_STAMP(i) do { if (tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_fuse_stamps[i], (unsigned long long)(now_ - stamp_)); stamp_ = now_; } } while (0)
+#else
+#define FUSE_STAMP(i) do { } while (0)
+#endif
+// (six waves per SIMD: at most 80 VGPRs, so that its waves fit beside the compose kernel's)
+__global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
                                                            int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
   __shared__ uint32_t s_c[kFuseCH][kFuseCW];
+  __shared__ int s_first[kFuseMaxSamples + 1];  // tiles of the samples before sample i
   const int TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int s = 0, first = 0;  // tiles of the samples before s
-  for (int t = blockIdx.x;; t += gridDim.x) {
-    int tcols = 0, ntiles = 0;
-    for (; s < n_samples; ++s) {  // the sample that holds tile t (t only grows: every workgroup walks the samples once)
-      const DevBgPrep& q = prep[s];
-      const bool fits = q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch;
-      if (!fits && blockIdx.x == 0 && tid == 0) atomicOr(err, kErrBgPrepCapacity);
-      tcols = fits ? (q.rx1 - q.rx0 + kFuseW) / kFuseW : 0;
-      ntiles = fits ? tcols * ((q.ry1 - q.ry0 + kFuseH) / kFuseH) : 0;
-      if (t < first + ntiles) break;
-      first += ntiles;
-    }
-    if (s >= n_samples) return;
-    const DevBgPrep p = prep[s];
-    const int ti = t - first, ty = ti / tcols, tx = ti - ty * tcols;
-    const int bx0 = p.rx0 + tx * kFuseW, bx1 = min(bx0 + kFuseW - 1, p.rx1);
-    const int by0 = p.ry0 + ty * kFuseH, by1 = min(by0 + kFuseH - 1, p.ry1);
-    int cx0, cx1, cy0, cy1;
-    cimg_resize_range(p.cw, TW, bx0, bx1, T.at_x, &cx0, &cx1);
-    cimg_resize_range(p.ch, TH, by0, by1, T.at_y, &cy0, &cy1);
-    const int ncw = cx1 - cx0 + 1, nch = cy1 - cy0 + 1;
-    if (ncw > kFuseCW || nch > kFuseCH) {  // (a crop beyond 4/3 of the texture: the host launches the two-kernel form for such pools)
-      if (tid == 0) atomicOr(err, kErrBgPrepCapacity);
-      continue;
-    }
-    // C(i, j), texel pairs
-    const int pairs = (ncw + 1) / 2;
-    const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48 (pairs <= 45; both factors below 2^24)
-    // The usual tile: its crop coordinates need no mirroring and its four corners - so, the map being affine, all its texels
-    // (a margin of one texel covers the rounding of the per-texel evaluation) - lie inside the source image: no per-texel tests.
-    bool inside = bgprep_shift_plain(p) && p.x0 + cx0 >= 0 && p.x0 + cx1 + 1 < p.rw && p.y0 + cy0 >= 0 && p.y0 + cy1 < p.rh;
-    if (inside) {
-      const float xa = __fsub_rn((float)(p.x0 + cx0), p.rw2), xb = __fsub_rn((float)(p.x0 + cx1 + 1), p.rw2);
-      const float ya = __fsub_rn((float)(p.y0 + cy0), p.rh2), yb = __fsub_rn((float)(p.y0 + cy1), p.rh2);
-      const RotPair ra = bgprep_rot_coords(p, xa, xb, ya), rb = bgprep_rot_coords(p, xa, xb, yb);
-      const float lo_x = fminf(fminf(ra.mx.x, ra.mx.y), fminf(rb.mx.x, rb.mx.y)), hi_x = fmaxf(fmaxf(ra.mx.x, ra.mx.y), fmaxf(rb.mx.x, rb.mx.y));
-      const float lo_y = fminf(fminf(ra.my.x, ra.my.y), fminf(rb.my.x, rb.my.y)), hi_y = fmaxf(fmaxf(ra.my.x, ra.my.y), fmaxf(rb.my.x, rb.my.y));
-      inside = lo_x >= 1.f && hi_x < (float)(p.pw - 2) && lo_y >= 1.f && hi_y < (float)(p.ph - 2);
-    }
-    if (inside) {
-      for (int k = tid; k < pairs * nch; k += 256) {
-        const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-        const int pi = k - jj * pairs;
-        const int xi = p.x0 + cx0 + 2 * pi;
-        const RotPair r = bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + jj), p.rh2));
-        *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_inside2(p, r, true);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
+#ifdef OFDG_FUSE_STAMPS
+  long long stamp_ = wall_clock64();
+#endif
+  // ---- the tiles of all samples are numbered consecutively: prefix of their counts (wave 0, 64 samples at a time) ----
+  if (wave == 0) {
+    int running = 0;
+    if (lane == 0) s_first[0] = 0;
+    for (int c = 0; c < n_samples; c += 64) {
+      const int i = c + lane;
+      int nt = 0;
+      if (i < n_samples) {
+        const DevBgPrep& q = prep[i];
+        const bool fits = fuse_sample_fits(q, cap_cw, cap_ch);
+        if (!fits && blockIdx.x == 0) atomicOr(err, kErrBgPrepCapacity);
+        nt = fits ? fuse_tile_cols(q) * ((q.ry1 - q.ry0 + kFuseH) / kFuseH) : 0;
       }
-    } else
-    for (int k = tid; k < pairs * nch; k += 256) {
-      const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-      const int pi = k - jj * pairs;
-      const int i = cx0 + 2 * pi, j = cy0 + jj;
-      const bool second = i + 1 <= cx1;
-      const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
-      const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-      const uint2 v = bgprep_rot_sample2(p, xc0, xc1, yc, second);
-      *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = v;
+      const int incl = wave_scan_incl(nt);
+      if (i < n_samples) s_first[i + 1] = running + incl;
+      running += __shfl(incl, 63, 64);
     }
-    __syncthreads();
-    // M(x, j) over C(., j), in place: wave w takes rows w, w + 4, ...; lane = column of the tile
+  }
+  __syncthreads();
+  // (what is read from LDS or through a vector load is a per-lane value to the compiler: readfirstlane says "uniform",
+  //  so that sample records are fetched by scalar loads and tile descriptors live in scalar registers)
+  const int total = __builtin_amdgcn_readfirstlane(s_first[n_samples]);
+  auto sample_of = [&](int t, int s) {  // t only grows: s walks the samples once
+    while (s < n_samples && t >= __builtin_amdgcn_readfirstlane(s_first[s + 1])) ++s;
+    return s;
+  };
+  // resize-table entry [n * dim + k] of a source length n (rows n >= dim do not exist: no table is used for them)
+  auto tab_index = [](int n, int dim, int k) { return (uint32_t)(n < dim ? n * dim + k : 0); };
+  // the fields of a sample's record that place a tile in B and pick its rows of the resize tables
+  struct PrepBox { int cw, ch, rx0, ry0, rx1, ry1; };
+  typedef OFDG_CONSTANT const DevBgPrep ConstPrep;  // (see below)
+  auto box_fields = [&](int s) { const ConstPrep& q = ((ConstPrep*)prep)[s]; return PrepBox{q.cw, q.ch, q.rx0, q.ry0, q.rx1, q.ry1}; };
+  auto box_of = [&](const PrepBox& q, int t, int s, FuseTile& F) {  // the tile's texels of B
+    const int tcols = (q.rx1 - q.rx0 + kFuseW) / kFuseW;
+    const int ti = t - __builtin_amdgcn_readfirstlane(s_first[s]), ty = ti / tcols, tx = ti - ty * tcols;
+    F.s = s;
+    F.bx0 = q.rx0 + tx * kFuseW; F.bx1 = min(F.bx0 + kFuseW - 1, q.rx1);
+    F.by0 = q.ry0 + ty * kFuseH; F.by1 = min(F.by0 + kFuseH - 1, q.ry1);
+  };
+  int t = blockIdx.x;
+  if (t >= total) return;
+  FuseTile cur;
+  int ex0, ex1, ey0, ey1;  // the four table entries that bound the tile's piece of C (requested one tile ahead)
+  {  // the first tile: nothing to overlap its loads with
+    const int s0 = sample_of(t, 0);
+    const PrepBox q = box_fields(s0);
+    box_of(q, t, s0, cur);
+    ex0 = __builtin_amdgcn_readfirstlane((int)T.at_x[tab_index(q.cw, TW, cur.bx0)]); ex1 = __builtin_amdgcn_readfirstlane((int)T.at_x[tab_index(q.cw, TW, cur.bx1)]);
+    ey0 = __builtin_amdgcn_readfirstlane((int)T.at_y[tab_index(q.ch, TH, cur.by0)]); ey1 = __builtin_amdgcn_readfirstlane((int)T.at_y[tab_index(q.ch, TH, cur.by1)]);
+  }
+  for (;;) {
+    // ---- S1: this tile's sample record and the placement fields of the next tile's (scalar loads, one wait for both).
+    // The records are constant while this kernel runs: read through the CONSTANT address space they are fetched by scalar
+    // loads even behind the kernel's own stores, which the compiler must otherwise assume could alias them. ----
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < total;
+    const int sc = __builtin_amdgcn_readfirstlane(cur.s);
+    const int sn = __builtin_amdgcn_readfirstlane(more ? sample_of(tn, sc) : sc);
+    const DevBgPrep p = ((ConstPrep*)prep)[sc];
+    const PrepBox qn = box_fields(sn);
+    // ---- S3 (of the previous iteration's requests): this tile's piece of C and its "inside" flag ----
+    fuse_finish_tile(p, cur, TW, TH, ex0, ex1, ey0, ey1);
+    const int bx0 = cur.bx0, bx1 = cur.bx1, by0 = cur.by0, by1 = cur.by1;
+    const int cx0 = cur.cx0, cx1 = cur.cx1, cy0 = cur.cy0;
+    const int ncw = cx1 - cx0 + 1, nch = cur.cy1 - cy0 + 1;
+    // ---- B: this tile's table entries: column x of the X pass (per lane), the wave's rows of the Y pass (lane r) ----
     const int x = bx0 + lane;
-    const uint16_t* at_x = T.at_x + (size_t)p.cw * TW;
-    const double* alpha_x = T.alpha_x + (size_t)p.cw * TW;
-    for (int jj = wave; jj < nch; jj += 4) {
-      uint32_t m = 0;
-      if (x <= bx1) m = cimg_resize_texel(p.cw, TW, x, at_x, alpha_x, [&](int i) { return s_c[jj][i - cx0]; });
-      __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
-      if (x <= bx1) s_c[jj][lane] = m;
+    const uint32_t ix = tab_index(p.cw, TW, min(x, bx1));
+    const int xa0 = T.at_x[ix];
+    const double xal = T.alpha_x[ix];
+    const uint32_t iy = tab_index(p.ch, TH, min(by0 + wave * kFuseRows + (lane & (kFuseRows - 1)), by1));
+    const int ya0v = T.at_y[iy];
+    const double yalv = T.alpha_y[iy];
+    // ---- S2: the next tile's box, and the four table entries that bound its piece of C (used at the top of its turn) ----
+    FuseTile nxt = cur;
+    int vx0 = 0, vx1 = 0, vy0 = 0, vy1 = 0;
+    if (more) {
+      box_of(qn, tn, sn, nxt);
+      vx0 = T.at_x[tab_index(qn.cw, TW, nxt.bx0)]; vx1 = T.at_x[tab_index(qn.cw, TW, nxt.bx1)];
+      vy0 = T.at_y[tab_index(qn.ch, TH, nxt.by0)]; vy1 = T.at_y[tab_index(qn.ch, TH, nxt.by1)];
     }
-    __syncthreads();
-    // B(x, y) over M(x, .): wave w takes rows 8 w .. 8 w + 7 of the tile
-    const uint16_t* at_y = T.at_y + (size_t)p.ch * TH;
-    const double* alpha_y = T.alpha_y + (size_t)p.ch * TH;
-    uint32_t* Bs = B + (size_t)s * TW * TH;
-    if (x <= bx1) {
-      for (int r = 0; r < kFuseH / 4; ++r) {
-        const int y = by0 + wave * (kFuseH / 4) + r;
-        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel(p.ch, TH, y, at_y, alpha_y, [&](int j) { return s_c[j - cy0][lane]; });
+    FUSE_STAMP(0);
+    if (!cur.fits) {  // (a crop beyond 4/3 of the texture: the host launches the two-kernel form for such pools)
+      if (tid == 0) atomicOr(err, kErrBgPrepCapacity);
+    } else {
+      // ---- rotation pass: C(i, j), texel pairs ----
+      const int pairs = (ncw + 1) / 2;
+      const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48 (pairs <= 45; both factors below 2^24)
+      if (cur.inside) {
+#ifdef OFDG_FUSE_UNROLL
+#pragma unroll OFDG_FUSE_UNROLL
+#endif
+        for (int k = tid; k < pairs * nch; k += kFuseThreads) {
+          const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+          const int pi = k - jj * pairs;
+          const int xi = p.x0 + cx0 + 2 * pi;
+          const RotPair r = bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + jj), p.rh2));
+          *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_inside2(p, r, true);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
+        }
+      } else {
+        for (int k = tid; k < pairs * nch; k += kFuseThreads) {
+          const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+          const int pi = k - jj * pairs;
+          const int i = cx0 + 2 * pi, j = cy0 + jj;
+          const bool second = i + 1 <= cx1;
+          const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+          const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+          const uint2 v = bgprep_rot_sample2(p, xc0, xc1, yc, second);
+          *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = v;
+        }
       }
     }
+    FUSE_STAMP(1);
+    __syncthreads();
+    FUSE_STAMP(2);
+    // (the entries requested in S2 have arrived behind the rotation pass's own loads; taken over into scalar registers here,
+    //  before this tile's stores: vmcnt counts loads and stores in order, a later wait would also wait for the stores)
+    ex0 = __builtin_amdgcn_readfirstlane(vx0); ex1 = __builtin_amdgcn_readfirstlane(vx1);
+    ey0 = __builtin_amdgcn_readfirstlane(vy0); ey1 = __builtin_amdgcn_readfirstlane(vy1);
+    if (cur.fits) {
+      // ---- X pass: M(x, j) over C(., j), in place: wave w takes rows w, w + 4, ...; lane = column of the tile ----
+      for (int jj = wave; jj < nch; jj += kFuseWaves) {
+        uint32_t m = 0;
+        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, [&](int i) { return s_c[jj][i - cx0]; });
+        __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
+        if (x <= bx1) s_c[jj][lane] = m;
+      }
+    }
+    __syncthreads();
+    FUSE_STAMP(3);
+    if (cur.fits && x <= bx1) {
+      // ---- Y pass: B(x, y) over M(x, .): wave w takes rows kFuseRows w .. of the tile ----
+      uint32_t* Bs = B + (size_t)cur.s * TW * TH;
+#pragma unroll
+      for (int r = 0; r < kFuseRows; ++r) {
+        const int y = by0 + wave * kFuseRows + r;
+        const int ya0 = __builtin_amdgcn_readlane(ya0v, r);  // (lane r holds row r's entry)
+        const double yal = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yalv), r), __builtin_amdgcn_readlane(__double2loint(yalv), r));
+        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, [&](int j) { return s_c[j - cy0][lane]; });
+      }
+    }
+    FUSE_STAMP(4);
+    if (!more) break;
     __syncthreads();  // (the next tile overwrites the rows)
+    FUSE_STAMP(5);
+#ifdef OFDG_FUSE_STAMPS
+    if (tid == 0) atomicAdd(&g_fuse_stamps[7], 1ull);
+#endif
+    cur = nxt;
+    t = tn;
   }
 }
 

@@ -126,10 +126,14 @@ struct TexSource {
 
 // Pointers the kernels read out of records are typed as GLOBAL memory in device code (a pointer loaded from memory is
 // generic otherwise: flat_load, which also counts on lgkmcnt and so serialises with every scalar wait).
+// OFDG_CONSTANT: memory no kernel writes while it runs; a uniform load from it is a scalar load even behind the kernel's own
+// stores (which the compiler must otherwise assume could alias it).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OFDG_GLOBAL __attribute__((address_space(1)))
+#define OFDG_CONSTANT __attribute__((address_space(4)))
 #else
 #define OFDG_GLOBAL
+#define OFDG_CONSTANT
 #endif
 // One served warp crop as the kernels see it (mode 9).
 struct DevCropRef {

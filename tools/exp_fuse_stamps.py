@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Developer experiment: where a tile of bgprep_fused_kernel spends its time (a library built with -DOFDG_FUSE_STAMPS:
+tools/build_variant.sh stamps -DOFDG_FUSE_STAMPS ...; OFDG_LIB=.../libofdg_stamps.so).  Wall-clock ticks of wave 0 of every
+workgroup per pass, alone (one chain) and in the pipeline (four chains)."""
+import ctypes as C, importlib, os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
+names = ["top: records, this tile's piece of C, table requests", "rotation pass", "barrier", "X resize + barrier", "Y resize", "barrier", "-"]
+outs = [ofdg.alloc_outputs(32, 384, 512) for _ in range(8)]
+for chains in (1, 4):
+    g = ofdg.Generator(ofdg.default_params(width=512, height=384, mode=5, num_objects=16, batch_size=32, sampler=1, seed=20261003, background_prep=1, chains=chains))
+    g.pool_synthetic(1000, 1024, 768, 2024)
+    buf = (C.c_ulonglong * 8)()
+    for i in range(40): g.forward(*outs[i % 8], g.next_stream())
+    g.synchronize()
+    ofdg.lib().ofdg_debug_fuse_stamps(buf)
+    n = 200
+    for i in range(n): g.forward(*outs[i % 8], g.next_stream())
+    g.synchronize()
+    ofdg.lib().ofdg_debug_fuse_stamps(buf)
+    tiles = buf[7]
+    print("chains %d: %d tiles per launch; per tile of one workgroup (us):" % (chains, tiles // n), "  ".join("%s %.2f" % (nm, buf[i] / tiles / 100.0) for i, nm in enumerate(names)),
+          " total %.2f" % (sum(buf[:7]) / tiles / 100.0), flush=True)
+    g.close()

@@ -256,9 +256,16 @@ int ofdg_num_chains(const ofdg_ctx* ctx);
  * device-side error flags raised by kernels. */
 int ofdg_synchronize(ofdg_ctx* ctx, void* stream);
 
-/* The same device-side error flags WITHOUT waiting for anything in flight: what a prefetch ring calls when it
- * hands over a batch whose own completion event it has waited for (prefetch_full_.pop, LAY:269). */
+/* The same device-side error flags WITHOUT waiting for anything in flight (all batches rendered so far). */
 int ofdg_poll_errors(ofdg_ctx* ctx);
+/* ... and per batch.  Every render / forward call has a number in its context ("ticket", ofdg_last_ticket right after the
+ * call) and raises its device flags in a word of its own: ofdg_poll_errors_of(ticket) says whether THAT batch was truncated
+ * (OFDG_ECAPACITY, the message names the batch) - what a prefetch ring calls when it hands over a batch whose own completion
+ * event it has waited for (prefetch_full_.pop, LAY:269), so that an error of batch k is reported at batch k's Forward, not
+ * at an older batch's, and batches k - 1 and k + 1 stay valid.  (The reference drops a bad sample silently, DG:1285-1292.)
+ * The flags of the last 256 calls are kept; reading a word clears it. */
+long long ofdg_last_ticket(const ofdg_ctx* ctx);
+int ofdg_poll_errors_of(ofdg_ctx* ctx, long long ticket);
 
 /* ---- mode 9 (non-rigid deformation) warp fields: replaces WarpFields::CropGenerator
  * (WF:469-641), which DataGenerator::Start launches for MODE == 9 (DG:1016-1020). ---- */

@@ -94,7 +94,7 @@ EXPORTS = [
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
-    "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_num_chains",
+    "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_poll_errors_of", "ofdg_last_ticket", "ofdg_num_chains",
     "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
     "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_abort", "ofdg_comm_nccl_count", "ofdg_comm_bcast_pool", "ofdg_comm_agree", "ofdg_setup_of", "ofdg_setup_params",
     "ofdg_setup_alloc_pool", "ofdg_pool_device_mixed", "ofdg_pool_device_image", "ofdg_layer_create_dist",
@@ -179,6 +179,9 @@ def lib():
         L.ofdg_layer_destroy.restype = None
         L.ofdg_layer_in_flight.argtypes = [vp]
         L.ofdg_poll_errors.argtypes = [vp]
+        L.ofdg_poll_errors_of.argtypes = [vp, C.c_longlong]
+        L.ofdg_last_ticket.argtypes = [vp]
+        L.ofdg_last_ticket.restype = C.c_longlong
         L.ofdg_num_chains.argtypes = [vp]
         L.ofdg_comm_unique_id.argtypes = [vp]
         L.ofdg_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
@@ -388,6 +391,18 @@ class Generator:
 
     def synchronize(self, stream=0):
         self._check(lib().ofdg_synchronize(self.h, C.c_void_p(stream)))
+
+    def last_ticket(self):
+        """Number of the batch the last render / forward call enqueued (its own device error word: poll_errors_of)."""
+        return int(lib().ofdg_last_ticket(self.h))
+
+    def poll_errors(self):
+        """Device error flags of every batch rendered so far, without waiting for anything in flight."""
+        self._check(lib().ofdg_poll_errors(self.h))
+
+    def poll_errors_of(self, ticket):
+        """Was THAT batch truncated (raises ECAPACITY)?  Call it after the batch's own completion event."""
+        self._check(lib().ofdg_poll_errors_of(self.h, ticket))
 
     @property
     def step(self):

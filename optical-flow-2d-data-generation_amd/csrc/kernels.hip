@@ -2282,8 +2282,14 @@ __global__ void debug_dda_kernel(Mat inv, int rows, int len, int2* __restrict__ 
   out[i] = make_int2(dda_at(R.x1, R.lx, R.rx, len, nshift, x), dda_at(R.y1, R.ly, R.ry, len, nshift, x));
 }
 
-// ofdg_poll_errors: read and clear the device error word in one step
-__global__ void err_exchange_kernel(uint32_t* __restrict__ d_err, uint32_t* __restrict__ out) { *out = atomicExch(d_err, 0u); }
+// ofdg_poll_errors / ofdg_poll_errors_of: read and clear n device error words in one step (one wave), *out = their OR
+__global__ void err_exchange_kernel(uint32_t* __restrict__ d_err, int n, uint32_t* __restrict__ out) {
+  uint32_t e = 0;
+  for (int i = (int)threadIdx.x; i < n; i += 64) e |= atomicExch(d_err + i, 0u);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) e |= (uint32_t)__shfl_xor((int)e, d, 64);
+  if (threadIdx.x == 0) *out = e;
+}
 
 __global__ void detmath_kernel(const double* __restrict__ a, int n, double* __restrict__ s, double* __restrict__ c,
                                const float* __restrict__ x, int m, float* __restrict__ e) {

@@ -347,6 +347,7 @@ void DataGenerationLayer::enqueue_next() {
     throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
   if (hipEventRecord((hipEvent_t)ring_done_[(size_t)(produced_ % P)], (hipStream_t)chain) != hipSuccess)
     throw std::runtime_error("DataGenerationLayer::Forward: hipEventRecord failed");
+  ring_ticket_[(size_t)(produced_ % P)] = ofdg_last_ticket(ctx_);
   ++produced_;
 }
 
@@ -362,6 +363,7 @@ void DataGenerationLayer::LayerSetUp(const std::vector<Blob*>& bottom, const std
       if (hipMalloc((void**)&ring_[k], (size_t)N * (k % 3 == 2 ? 2 : 3) * H * W * sizeof(float)) != hipSuccess)
         throw std::runtime_error("DataGenerationLayer: hipMalloc of the prefetch buffers failed");
     ring_done_.assign((size_t)P, nullptr);
+    ring_ticket_.assign((size_t)P, -1);
     for (int k = 0; k < P; ++k)
       if (hipEventCreateWithFlags((hipEvent_t*)&ring_done_[k], hipEventDisableTiming) != hipSuccess)
         throw std::runtime_error("DataGenerationLayer: hipEventCreate failed");
@@ -389,7 +391,9 @@ void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const st
     // wait for THIS set's event only: the batches behind it keep rendering
     if (hipEventSynchronize((hipEvent_t)ring_done_[(size_t)(consumed_ % P)]) != hipSuccess)
       throw std::runtime_error("DataGenerationLayer::Forward: hipEventSynchronize failed");
-    if (ofdg_poll_errors(ctx_) != OFDG_OK) throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+    // THIS batch's device error flags (a flag raised by a younger batch still rendering is reported at that batch's own turn)
+    if (ofdg_poll_errors_of(ctx_, ring_ticket_[(size_t)(consumed_ % P)]) != OFDG_OK)
+      throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
     float** set = &ring_[(size_t)(consumed_ % P) * 3];
     for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
     ++consumed_;

@@ -87,6 +87,7 @@ class DataGenerationLayer {
   ofdg_ctx* ctx_ = nullptr;
   std::vector<float*> ring_;       // [prefetch][3] device buffers (prefetch > 1)
   std::vector<void*> ring_done_;   // [prefetch] hipEvent_t: the set's batch is complete
+  std::vector<long long> ring_ticket_;  // ... and the batch's number in the context (its own device error word)
  public:
   // batches rendered ahead that had not finished when the last Forward returned (diagnostics / tests)
   int in_flight_after_last_forward() const { return in_flight_; }

@@ -137,6 +137,7 @@ struct ofdg_ctx {
       const DevCropRef* croptab = nullptr;
       hipEvent_t* ev = nullptr;    // profiled launch: its event set
       hipStream_t stream = nullptr;  // where the preparation was enqueued
+      long long ticket = -1;       // the batch's number (its error word)
     } prep;
   };
   static constexpr int kMaxChains = 8;
@@ -154,6 +155,7 @@ struct ofdg_ctx {
   DevBuf<ofdg_blueprint> d_cs_bps;
   DevBuf<int> d_cs_nobj;
   long long next_index = 0;  // next global sample index of this rank's stream
+  long long last_ticket = -1;  // ticket of the batch the last render / forward call composed
   // mode 9: served warp crops, each 4 planes of (W+1)*(H+1) floats, contiguous
   float* d_warp = nullptr;         // [n_crops][2 pairs][(H+1)][(W+1)][2]: (flow x, flow y), (iflow x, iflow y) interleaved
   unsigned* d_warp_max = nullptr;  // [n_crops] float bits of max |iflow|
@@ -168,7 +170,13 @@ struct ofdg_ctx {
   double *d_rs_xa = nullptr, *d_rs_ya = nullptr;
   bool overlap = true;
   double* d_cs_tab = nullptr;
-  uint32_t* d_err = nullptr;
+  // Device error flags, ONE WORD PER CALL: call number q ("ticket") raises its flags in word q mod kErrWords, so that a prefetch
+  // ring can ask at a batch's hand-over whether THAT batch was truncated (ofdg_poll_errors_of) - the reference drops a bad
+  // sample silently (DG:1285-1292).  A word is cleared when it is read; one that was never asked for is read by
+  // ofdg_synchronize / ofdg_poll_errors, or together with the call that takes the word over kErrWords calls later.
+  static constexpr int kErrWords = 256;
+  uint32_t* d_err = nullptr;     // [kErrWords]
+  long long ticket = 0;          // calls made so far = the ticket of the next call
   // background_prep = 1: CImg's enlarging tables for every source length below 2W (x) / 2H (y), tabulated once
   DevBuf<uint16_t> d_bg_at_x, d_bg_at_y;
   DevBuf<double> d_bg_alpha_x, d_bg_alpha_y;
@@ -183,6 +191,7 @@ struct ofdg_ctx {
   std::vector<hipEvent_t> ev;
   int ev_sets = 0, ev_stride = 1;
   long long ev_count = 0, ev_alloc = 0, launch_count = 0;  // event sets: composed / handed out (a prepared batch holds one)
+  std::vector<char> ev_composed;  // per set: its compose was enqueued (a prepared batch that is discarded leaves its set incomplete)
   std::vector<ofdg_task> fw_tasks;
   std::vector<ofdg_blueprint> fw_bps;
 };
@@ -195,6 +204,17 @@ struct ofdg_ctx {
       return OFDG_EHIP;                                                                       \
     }                                                                                         \
   } while (0)
+
+// the error word of the call being made (its ticket is taken - c->ticket advanced - when the call's first kernel is enqueued)
+static uint32_t* err_word(ofdg_ctx* c, long long ticket) { return c->d_err + (size_t)(ticket % ofdg_ctx::kErrWords); }
+static std::string err_text(uint32_t e) {
+  std::string t = "device capacity exceeded:";
+  if (e & kErrVertCapacity) t += " outline vertices > 1024;";
+  if (e & kErrCurveCapacity) t += " curve3 subdivision points/depth;";
+  if (e & kErrDxLimit) t += " edge spans >= 16384 px;";
+  if (e & kErrBgPrepCapacity) t += " background_prep: crop of the rotated image exceeds the workspace (zoom < 0.75);";
+  return t;
+}
 
 static void drop_counter_croptab(ofdg_ctx* c);
 static int discard_all_prepared(ofdg_ctx* c);
@@ -286,8 +306,8 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   }
   if ((e = hipMalloc((void**)&c->d_cs_tab, sizeof(tab))) != hipSuccess ||
       (e = hipMemcpy(c->d_cs_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMalloc((void**)&c->d_err, sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_err, ofdg_ctx::kErrWords * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMemset(c->d_err, 0, ofdg_ctx::kErrWords * sizeof(uint32_t))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->user_stage.free_ev, hipEventDisableTiming)) != hipSuccess) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
@@ -827,18 +847,18 @@ static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes) {
 
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s);
-static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s) {
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s, uint32_t* err);
+static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, uint32_t* err) {
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
                   c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin,
                   (unsigned long long)(uintptr_t)c->pool, c->d_tex_table};
   hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
-                     sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, c->d_err, sl.d_bgprep.p);
+                     sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
   if (prep) {
-    int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s);
+    int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s, err);
     if (rc != OFDG_OK) return rc;
   }
   return OFDG_OK;
@@ -889,9 +909,14 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   const int n_sf = sl.res_shapes * 2;
   const RenderDims dm = render_dims(c, sl);
   { int rc = discard_prepared(c, ch); if (rc != OFDG_OK) return rc; }
+  const long long ticket = c->ticket++;  // this batch's number: its kernels raise their flags in its own word
+  uint32_t* const err = err_word(c, ticket);
   hipEvent_t* ev = nullptr;
-  if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0)
-    ev = &c->ev[(size_t)(c->ev_alloc++ % c->ev_sets) * 6];
+  if (c->profiling && c->ev_sets > 0 && (c->launch_count % c->ev_stride) == 0) {
+    const size_t set = (size_t)(c->ev_alloc++ % c->ev_sets);
+    ev = &c->ev[set * 6];
+    c->ev_composed[set] = 0;
+  }
   c->launch_count++;
   if (!c->overlap) {
     // everything runs on the caller's stream; a caller that switches streams loses the ordering
@@ -918,7 +943,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
   const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
   if (cs_first_index >= 0) {  // device counter sampler + device realize
-    int rc = launch_counter_sampler(c, sl, cs_first_index, S);
+    int rc = launch_counter_sampler(c, sl, cs_first_index, S, err);
     if (rc != OFDG_OK) return rc;
   }
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
@@ -931,12 +956,12 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   const bool prof_prep = ev && c->profiling == 2;
   // Profiled launches: a kernel's time is the span between the completion of its predecessor on the
   // chain's stream and its own completion - both taken from the kernels' own dispatch packets (stop
-  // events).  A start event would be a marker packet in front of the kernel, which delays its dispatch
-  // by ~10 us and is then counted as kernel time; only geom (first of the three) has one.
+  // events).  A start event is a marker packet in front of the kernel, which delays its dispatch by
+  // ~6-10 us: geom (first of the three) and compose (ev[4], launch_compose) have one, raster has none.
   // geom: outlines, boxes, raster work list -> raster: coverage slots + block masks (persistent waves over the list)
   hipExtLaunchKernelGGL(geom_kernel, dim3(std::max(1, (n_sf + kGeomWaves - 1) / kGeomWaves)), dim3(64 * kGeomWaves), 0, S,
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
-                        sl.d_frames.p, sl.d_verts.p, box_cur, c->d_err, sl.d_item_count, sl.d_items.p, croptab);
+                        sl.d_frames.p, sl.d_verts.p, box_cur, err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
   // (a compose on a caller's stream takes the prepared batch over with the event on raster's own packet)
   hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
@@ -945,7 +970,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   HIP_OK(c, hipGetLastError());
   if (ev && hand_over) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
   ch.prep.valid = true; ch.prep.slot = &sl; ch.prep.first_index = cs_first_index; ch.prep.n = sl.res_samples;
-  ch.prep.box_cur = box_cur; ch.prep.croptab = croptab; ch.prep.ev = ev; ch.prep.stream = S;
+  ch.prep.box_cur = box_cur; ch.prep.croptab = croptab; ch.prep.ev = ev; ch.prep.stream = S; ch.prep.ticket = ticket;
   return OFDG_OK;
 }
 
@@ -962,13 +987,14 @@ static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float
   unsigned long long* box_cur = ch.prep.box_cur;
   const DevCropRef* croptab = ch.prep.croptab;
   uint8_t* cov = ch.cov.p;
-  c->last_slot = &sl;
-  ch.prep.valid = false;
   const hipStream_t S = ch.prep.stream;
   const bool foreign = S != st;  // the caller's stream is not the chain's
   const uint32_t* bgpool = c->prm.background_prep ? sl.d_bgtex.p : (c->pool_bg ? c->pool_bg : c->pool);  // (after the slot's buffers are final)
   const uint32_t* fgpool = c->pool_fg ? c->pool_fg : c->pool;
   if (c->prm.background_prep && !bgpool) { c->err = "background_prep: the slot has no prepared backgrounds"; return OFDG_EINVAL; }
+  c->last_slot = &sl;
+  c->last_ticket = ch.prep.ticket;
+  ch.prep.valid = false;  // (consumed from here on; an argument error above leaves it to discard_prepared, which resets the work list)
   // Where compose runs: on the chain's stream, right behind the preparation - or, if the caller passed another stream,
   // on THAT stream (in order with the caller's own work, which may still read the outputs) once the batch is prepared.
   // It is tracked by the chain's event whenever somebody else may have to wait for it: the chain
@@ -1002,6 +1028,7 @@ static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float
   if (ev) {
     if (done) HIP_OK(c, hipEventRecord(done, CS));
     c->ev_count++;
+    c->ev_composed[(size_t)(ev - c->ev.data()) / 6] = 1;
   }
   if (done) {
     sl.compose_pending = true; sl.compose_stream = CS; sl.compose_event = done;
@@ -1058,7 +1085,7 @@ static int ensure_bgprep_tables(ofdg_ctx* c) {
 
 // background_prep: (upload the records of n samples and) render their 2W x 2H background
 // textures into the slot's buffer on stream `s` (bgprep_kernel)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s) {
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s, uint32_t* err) {
   const int W = c->prm.width, H = c->prm.height;
   HIP_OK(c, sl.d_bgprep.reserve(n));
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
@@ -1086,13 +1113,13 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
   if (fusable && n <= kFuseMaxSamples) {
-    hipLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), 0, s, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, c->d_err);
+    hipLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), 0, s, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
   HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
   hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
-                     c->d_err);
+                     err);
   hipLaunchKernelGGL(bgprep_resize_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
                      sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
@@ -1185,7 +1212,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     HIP_OK(c, hipStreamSynchronize(st));  // `tab` is a stack vector
   }
   if (c->prm.background_prep) {
-    int rcb = prepare_backgrounds(c, sl, n_tasks, B.bgprep.data(), st);
+    int rcb = prepare_backgrounds(c, sl, n_tasks, B.bgprep.data(), st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
     if (rcb != OFDG_OK) return rcb;
   }
   HIP_OK(c, hipEventRecord(stage.free_ev, st));
@@ -1298,16 +1325,19 @@ int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, floa
   if (rc != OFDG_OK) return rc;
   rc = launch_compose(c, ch, d_img0, d_img1, d_flow, st);
   if (rc != OFDG_OK) return rc;
+  // (the caller's batch is composed: from here on the call has succeeded, whatever happens to the batches prepared ahead)
+  const long long prev_first = c->last_first;
+  c->last_first = first_index;
   if (c->overlap && c->lookahead > 0) {
-    const long long stride = (c->last_first >= 0 && first_index > c->last_first) ? first_index - c->last_first
-                                                                                   : (long long)n_samples * std::max(1, c->prm.world_size);
+    const long long stride = (prev_first >= 0 && first_index > prev_first) ? first_index - prev_first
+                                                                             : (long long)n_samples * std::max(1, c->prm.world_size);
     for (int d = 1; d <= std::min(c->lookahead, c->n_chains - 1); ++d) {
       ofdg_ctx::Chain& cj = c->chains[(k + d) % c->n_chains];
-      rc = prepare_on(cj, first_index + (long long)d * stride, cj.stream, true);  // (the stream of the call that composes it is not known yet)
-      if (rc != OFDG_OK) return rc;
+      // a preparation ahead that cannot be enqueued is dropped: the call that needs the batch prepares it itself and
+      // reports the failure if it persists
+      if (prepare_on(cj, first_index + (long long)d * stride, cj.stream, true) != OFDG_OK) { (void)discard_prepared(c, cj); break; }
     }
   }
-  c->last_first = first_index;
   return OFDG_OK;
 }
 
@@ -1419,15 +1449,20 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
     HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
     if (c->chains[k].done_pending) HIP_OK(c, hipEventSynchronize(c->chains[k].ev_done));  // (a compose on another caller stream)
   }
+  uint32_t words[ofdg_ctx::kErrWords];
+  HIP_OK(c, hipMemcpy(words, c->d_err, sizeof(words), hipMemcpyDeviceToHost));
   uint32_t e = 0;
-  HIP_OK(c, hipMemcpy(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost));
+  long long first_bad = -1;
+  for (int i = 0; i < ofdg_ctx::kErrWords; ++i)
+    if (words[i]) {
+      e |= words[i];
+      // the most recent call that used this word
+      const long long q = c->ticket - 1 - ((c->ticket - 1 - i) % ofdg_ctx::kErrWords + ofdg_ctx::kErrWords) % ofdg_ctx::kErrWords;
+      if (first_bad < 0 || q < first_bad) first_bad = q;
+    }
   if (e) {
-    HIP_OK(c, hipMemset(c->d_err, 0, sizeof(uint32_t)));
-    c->err = "device capacity exceeded:";
-    if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
-    if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
-    if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
-    if (e & kErrBgPrepCapacity) c->err += " background_prep: crop of the rotated image exceeds the workspace (zoom < 0.75);";
+    HIP_OK(c, hipMemset(c->d_err, 0, sizeof(words)));
+    c->err = err_text(e) + " (first in batch " + std::to_string(first_bad) + " of this context, or one " + std::to_string(ofdg_ctx::kErrWords) + " calls earlier)";
     return OFDG_ECAPACITY;
   }
   return OFDG_OK;
@@ -1435,26 +1470,39 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
 
 // The device-side error flags without waiting for anything in flight (a prefetch ring checks them when it hands
 // a finished batch over; flags of younger batches are reported at their own hand-over at the latest).
-int ofdg_poll_errors(ofdg_ctx* c) {
-  if (!c) return OFDG_EINVAL;
+static int poll_words(ofdg_ctx* c, int first, int n, uint32_t* flags) {
   if (!c->h_err) HIP_OK(c, hipHostMalloc((void**)&c->h_err, sizeof(uint32_t), hipHostMallocMapped));
   if (!c->err_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->err_stream, hipStreamNonBlocking));
-  // read AND clear in one atomic exchange (younger batches are still running and may raise a flag at any time: a copy
-  // followed by a memset would lose what is raised in between)
+  // read AND clear in one atomic exchange per word (younger batches are still running and may raise a flag at any time: a
+  // copy followed by a memset would lose what is raised in between)
   uint32_t* h_dev = nullptr;
   HIP_OK(c, hipHostGetDevicePointer((void**)&h_dev, c->h_err, 0));
-  hipLaunchKernelGGL(err_exchange_kernel, dim3(1), dim3(1), 0, c->err_stream, c->d_err, h_dev);
+  hipLaunchKernelGGL(err_exchange_kernel, dim3(1), dim3(64), 0, c->err_stream, c->d_err + first, n, h_dev);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->err_stream));
-  const uint32_t e = *c->h_err;
-  if (e) {
-    c->err = "device capacity exceeded:";
-    if (e & kErrVertCapacity) c->err += " outline vertices > 1024;";
-    if (e & kErrCurveCapacity) c->err += " curve3 subdivision points/depth;";
-    if (e & kErrDxLimit) c->err += " edge spans >= 16384 px;";
-    if (e & kErrBgPrepCapacity) c->err += " background_prep: crop of the rotated image exceeds the workspace (zoom < 0.75);";
-    return OFDG_ECAPACITY;
-  }
+  *flags = *c->h_err;
+  return OFDG_OK;
+}
+int ofdg_poll_errors(ofdg_ctx* c) {
+  if (!c) return OFDG_EINVAL;
+  uint32_t e = 0;
+  int rc = poll_words(c, 0, ofdg_ctx::kErrWords, &e);
+  if (rc != OFDG_OK) return rc;
+  if (e) { c->err = err_text(e); return OFDG_ECAPACITY; }
+  return OFDG_OK;
+}
+
+// The flags of ONE batch (ticket = ofdg_last_ticket() right after the call that rendered it), without waiting for anything:
+// what a prefetch ring asks when it hands that batch over, having waited for the batch's own completion event.  The word
+// is cleared.  Tickets older than kErrWords calls are gone (OFDG_EINVAL).
+long long ofdg_last_ticket(const ofdg_ctx* c) { return c ? c->last_ticket : -1; }
+int ofdg_poll_errors_of(ofdg_ctx* c, long long ticket) {
+  if (!c) return OFDG_EINVAL;
+  if (ticket < 0 || ticket >= c->ticket || ticket + ofdg_ctx::kErrWords <= c->ticket) { c->err = "ofdg_poll_errors_of: no such batch (tickets of the last " + std::to_string(ofdg_ctx::kErrWords) + " calls are kept)"; return OFDG_EINVAL; }
+  uint32_t e = 0;
+  int rc = poll_words(c, (int)(ticket % ofdg_ctx::kErrWords), 1, &e);
+  if (rc != OFDG_OK) return rc;
+  if (e) { c->err = "batch " + std::to_string(ticket) + ": " + err_text(e); return OFDG_ECAPACITY; }
   return OFDG_OK;
 }
 
@@ -1721,6 +1769,7 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
     c->ev.resize((size_t)c->ev_sets * 6);
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
   }
+  c->ev_composed.assign((size_t)c->ev_sets, 0);
   return OFDG_OK;
 }
 
@@ -1738,9 +1787,11 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
     c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)";
     return OFDG_EINVAL;
   }
-  const int n = (int)std::min<long long>(c->ev_count, c->ev_sets);
+  int n = 0;
   double acc = 0;
-  for (int k = 0; k < n; ++k) {
+  for (int k = 0; k < c->ev_sets; ++k) {
+    if (!c->ev_composed[(size_t)k]) continue;  // (never handed out, or its prepared batch was discarded before compose)
+    ++n;
     hipEvent_t* ev = &c->ev[(size_t)k * 6];
     HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
@@ -1748,6 +1799,7 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
     HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : (i == 2 ? 4 : 1)], ev[2 * i + 1]));
     acc += t;
   }
+  if (n == 0) { c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)"; return OFDG_EINVAL; }
   *ms = (float)(acc / n);
   return OFDG_OK;
 }

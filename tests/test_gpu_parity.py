@@ -751,6 +751,14 @@ def test_background_prep_full_size_and_counter_sampler(ofdg, oracle, prep):
         e0, e1, ef = oracle.render(q, tasks, 2, bps, n, host_pool)
     assert np.array_equal(i0.cpu().numpy(), e0) and np.array_equal(i1.cpu().numpy(), e1)
     assert ulp_diff(fl.cpu().numpy(), ef).max() == 0
+    # ... and against the oracle in its DEFAULT arithmetic - libm's fp64 sin / cos in the affines and, for the preparation
+    # record, float std::cos / std::sin as the reference (CImg) evaluates them: the north-star tolerance, <= 1 LSB per
+    # channel on a small share of the pixels and <= 1 ULP of flow
+    l0, l1, lf = oracle.render(q, tasks, 2, bps, n, host_pool)
+    for got, ref in ((i0.cpu().numpy(), l0), (i1.cpu().numpy(), l1)):
+        d = np.abs(got - ref)
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+    assert ulp_diff(fl.cpu().numpy(), lf).max() <= 1
 
 
 # ---- pool images smaller than the texture they feed (the resize branch of getRandomizedCrop, DG:102-106) ----
@@ -976,3 +984,54 @@ def test_end_to_end_fixture_on_the_gpu(ofdg, oracle):
         i0, i1, fl = render_gpu(ofdg, g, tasks, B, bps, n)
         assert gen.digest(i0) == sc["image0"] and gen.digest(i1) == sc["image1"], (mode, aa)
         assert gen.digest(fl) == sc["flow"], (mode, aa)
+
+
+def test_device_error_is_reported_at_its_own_batch(ofdg, oracle):
+    """One device error word per call (ofdg_last_ticket / ofdg_poll_errors_of): three batches in flight on a ring of three
+    buffer sets, the middle one with an outline whose curves overflow the flattening capacity (and whose edges span more
+    than AGG's dx_limit).  The error is reported at THAT batch's hand-over - not at the older batch's, although the flag is
+    already raised by then - and the batches before and after it are valid."""
+    torch = torch_mod()
+    W, H, B = 128, 96, 2
+    g = make_gen(ofdg, W, H, 5, num_objects=6)
+    smp = oracle.Sampler(5, W, H, 6)
+    batches = [smp.next(B) for _ in range(3)]
+    tasks, bps, n = batches[1]
+    victim = None
+    for k in range(tasks[0].n_objects):       # a polygon with a curve3 segment of sample 0
+        o = bps[tasks[0].first_object + k]
+        if o.obj_type == ofdg.OBJ_POLYGON and any(o.segment_type[i] == ofdg.SEG_CURVE3 for i in range(o.n_segments)):
+            victim = o
+            break
+    assert victim is not None, "the sampled batch holds no curved polygon: pick another seed"
+    victim.scale = 600.0                      # frame 1: the curve needs more than 96 points, the edges span > 16384 px
+    outs = [ofdg.alloc_outputs(B, H, W) for _ in range(3)]
+    tickets = []
+    for k, (t, b, nb) in enumerate(batches):  # all three in flight, each on the context's next chain
+        g.render(t, B, b, nb, *outs[k], g.next_stream())
+        tickets.append(g.last_ticket())
+    assert tickets == [tickets[0], tickets[0] + 1, tickets[0] + 2]
+    torch.cuda.synchronize()                  # every batch is complete: batch 1's flag is raised by now
+    g.poll_errors_of(tickets[0])              # ... and batch 0's hand-over does not see it
+    with pytest.raises(ofdg.OfdgError) as e:
+        g.poll_errors_of(tickets[1])
+    assert e.value.code == ofdg.ECAPACITY and "batch %d" % tickets[1] in str(e.value)
+    g.poll_errors_of(tickets[2])
+    g.poll_errors_of(tickets[1])              # (read once: the word is cleared)
+    g.synchronize()                           # nothing is left for the device-wide check either
+    # batches 0 and 2 are what a context that never saw the bad batch renders
+    g2 = make_gen(ofdg, W, H, 5, num_objects=6)
+    for k in (0, 2):
+        t, b, nb = batches[k]
+        ref = render_gpu(ofdg, g2, t, B, b, nb)
+        for a, r in zip(outs[k], ref):
+            assert np.array_equal(a.cpu().numpy(), r)
+    # a ticket that is too old (or not yet given out) is refused
+    with pytest.raises(ofdg.OfdgError) as e:
+        g.poll_errors_of(tickets[2] + 1)
+    assert e.value.code == ofdg.EINVAL
+    # the device-wide forms still see a flag nobody asked for by ticket
+    g.render(tasks, B, bps, n, *outs[1], g.next_stream())
+    with pytest.raises(ofdg.OfdgError) as e:
+        g.synchronize()
+    assert e.value.code == ofdg.ECAPACITY

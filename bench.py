@@ -20,7 +20,7 @@ over one batch of NEW samples:
       NSLOT realised batches are resident in HBM and rotated; a step is geom -> raster -> compose.
 
 The calls are made the way a prefetch ring makes them: call k renders into output buffer set k mod NBUF on the
-context's next internal stream (ofdg_stream); NBUF = 2 x the number of internal streams, so a buffer set is
+context's next internal stream (OFDG_STREAM_OWN); NBUF = 2 x the number of internal streams, so a buffer set is
 always written by the same in-order stream and the calls in flight never share an output.  The timed region
 ends with a device-wide synchronisation.
 
@@ -332,7 +332,7 @@ def timed_pass(ofdg, gen, cfg, pl, outs, steps, warmup, rank, world, stream):
     host_sampler_rate = None
     if cfg["sampler"] in ("counter", "ref"):
         def step(i):  # counter: samples (step*world + rank)*B + [0, B) on the device, then renders; ref (config 1): the
-            gen.forward(*outs[i % NBUF], gen.next_stream())  # reference-stream sampler on the host inside the step, like load_batch
+            gen.forward(*outs[i % NBUF], ofdg.STREAM_OWN)  # reference-stream sampler on the host inside the step, like load_batch
     else:
         # every rank walks the same reference stream and keeps its own block of each B*world tasks
         sampler = ofdg.HostSampler(cfg["mode"], cfg["W"], cfg["H"], cfg["nobj"])
@@ -344,7 +344,7 @@ def timed_pass(ofdg, gen, cfg, pl, outs, steps, warmup, rank, world, stream):
         host_sampler_rate = NSLOT * BATCH * world / (time.perf_counter() - t_s)
 
         def step(i):
-            gen.render_slot(i % NSLOT, *outs[i % NBUF], gen.next_stream())
+            gen.render_slot(i % NSLOT, *outs[i % NBUF], ofdg.STREAM_OWN)
     gen.synchronize(stream)
     for i in range(warmup):
         step(i)

@@ -195,6 +195,9 @@ int ofdg_sample(ofdg_ctx* ctx, int n_tasks, ofdg_task* tasks,
  * consecutive calls then overlap as well - the fast way to drive a prefetch ring:
  * one output buffer set per call in flight).
  */
+/* As a call's `stream`: "the internal stream this call works on" - the same as passing ofdg_stream(ctx) read right before
+ * the call, without the extra call. */
+#define OFDG_STREAM_OWN ((void*)(~(uintptr_t)0))
 int ofdg_render(ofdg_ctx* ctx, const ofdg_task* tasks, int n_tasks,
                 const ofdg_blueprint* bps, int n_bps,
                 float* d_image0, float* d_image1, float* d_flow, void* stream);
@@ -304,6 +307,13 @@ int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
 int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
 /* Number of raster work items the last launch left unprocessed (diagnostics: 0). */
 int ofdg_debug_item_count(ofdg_ctx* ctx);
+/* Experiment (tools/exp_graph.py): the kernels of one ofdg_forward_counter call on internal stream `chain`, captured into a
+ * HIP graph with their parameters frozen (replays render the SAME batch into the same buffers), to compare one
+ * hipGraphLaunch per step with the four launches of the product path on the real kernels. */
+int ofdg_debug_graph_capture(ofdg_ctx* ctx, int chain, long long first_index, int n_samples,
+                             float* d_image0, float* d_image1, float* d_flow, void** graph_exec);
+int ofdg_debug_graph_launch(ofdg_ctx* ctx, void* graph_exec, int chain);
+int ofdg_debug_graph_destroy(ofdg_ctx* ctx, void* graph_exec);
 /* Per-kernel device time (ms) of the last render, measured with HIP events on
  * the launch stream when profiling is enabled. names: "geom","raster","compose". */
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract

@@ -16,6 +16,7 @@ MAX_SEG = 20
 
 OK, EBADMODE, ETEXTURES, EOBJTYPE, EHIP, ECAPACITY, EINVAL, ESTARTUP = 0, -1, -2, -3, -4, -5, -6, -7
 OBJ_ELLIPSE, OBJ_POLYGON, OBJ_COMPOSITE = 1, 2, 3
+STREAM_OWN = (1 << 64) - 1  # OFDG_STREAM_OWN: as a call's `stream`, the internal stream that call works on (= next_stream())
 SEG_DUMMY, SEG_LINE, SEG_CURVE3 = 0, 1, 3
 
 
@@ -90,7 +91,7 @@ EXPORTS = [
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_shard_first_index", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
     "ofdg_debug_rasterize", "ofdg_debug_rasterize_path", "ofdg_debug_dda_rows", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_tables", "ofdg_debug_detmath",
-    "ofdg_set_profiling", "ofdg_kernel_ms",
+    "ofdg_set_profiling", "ofdg_kernel_ms", "ofdg_debug_graph_capture", "ofdg_debug_graph_launch", "ofdg_debug_graph_destroy",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
     "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",

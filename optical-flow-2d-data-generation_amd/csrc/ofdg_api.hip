@@ -33,15 +33,23 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
+  bool view = false;  // p points into another allocation (the record arena of an uploaded batch): not ours to free
   hipError_t reserve(size_t n) {
-    if (n <= cap) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    if (n <= cap && !view) return hipSuccess;
+    if (p && !view) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; }
+    p = nullptr; cap = 0; view = false;
     size_t want = n + n / 4 + 16;
     hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
     if (e == hipSuccess) cap = want;
     return e;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  // look at n elements of somebody else's memory (what we own is given up first)
+  hipError_t alias(T* q, size_t n) {
+    if (p && !view) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; }
+    p = q; cap = n; view = true;
+    return hipSuccess;
+  }
+  void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
 };
 
 struct ofdg_ctx {
@@ -78,6 +86,7 @@ struct ofdg_ctx {
     DevBuf<int2> d_verts;
     DevBuf<DevObject> d_objects;
     DevBuf<DevSample> d_samples;
+    DevBuf<char> d_rec;  // uploaded batches: shapes | objects | samples in ONE allocation (one copy per batch; the three above look into it)
     DevBuf<int4> d_items;
     DevBuf<DevBgPrep> d_bgprep;   // background_prep: one record ...
     DevBuf<uint32_t> d_bgtex;     // ... and one prepared 2W x 2H BGRX texture per sample
@@ -359,7 +368,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   for (uint32_t* im : c->mixed_images) if (im) (void)hipFree(im);
   if (c->d_tex_table) (void)hipFree(c->d_tex_table);
   auto drop_slot = [](ofdg_ctx::Slot& sl) {
-    sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release();
+    sl.d_shapes.release(); sl.d_frames.release(); sl.d_verts.release(); sl.d_objects.release(); sl.d_samples.release(); sl.d_rec.release();
     sl.d_items.release(); sl.d_blockmask.release(); sl.d_bgprep.release(); sl.d_bgtex.release();
     sl.d_bgC.release();
     sl.d_croptab.release(); sl.d_bgwarp.release(); sl.d_bgwarp_max.release();
@@ -864,6 +873,9 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
   return OFDG_OK;
 }
 
+// OFDG_STREAM_OWN as a call's `stream`: the internal stream that call works on (what ofdg_stream() returns right before it)
+static void* own_stream(ofdg_ctx* c, void* stream) { return stream == OFDG_STREAM_OWN ? ofdg_stream(c) : stream; }
+
 static ofdg_ctx::Chain& take_chain(ofdg_ctx* c) {
   const int k = (int)(c->next_chain % (unsigned)c->n_chains);
   c->next_chain++;
@@ -1127,8 +1139,9 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
 }
 
 // realise on the host, stage, and copy the records of one batch into slot `sl`
+//   `shared`: the slot may be rendered on other streams than `st` (a caller's slot): the upload is tracked by an event
 static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, int n_tasks, const ofdg_blueprint* bps,
-                       int n_bps, hipStream_t st, ofdg_ctx::Stage& stage) {
+                       int n_bps, hipStream_t st, ofdg_ctx::Stage& stage, bool shared) {
   if (!c->pool && !c->pool_mixed) { c->err = "Could not open texture collection (no texture pool)"; return OFDG_ETEXTURES; }
   { int rcf = finalise_pool(c); if (rcf != OFDG_OK) return rcf; }
   { int rct = ensure_tex_table(c); if (rct != OFDG_OK) return rct; }
@@ -1148,7 +1161,18 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   if (rc != OFDG_OK) return rc;
   const RealizedBatch& B = sl.batch;
   const size_t n_shapes = B.shapes.size(), n_obj = B.objects.size();
-  HIP_OK(c, sl.d_shapes.reserve(n_shapes));
+  // the batch's records - shapes | objects | samples - travel as ONE copy into one allocation (three copies cost the host
+  // 7 us a batch, one 2.5: tools/microbench/launch_cost.hip - most of what a batch of one sample costs)
+  const size_t b_shapes = (n_shapes * sizeof(DevShape) + 255) & ~(size_t)255, b_obj = (n_obj * sizeof(DevObject) + 255) & ~(size_t)255,
+               b_smp = (size_t)n_tasks * sizeof(DevSample);
+  const size_t need = b_shapes + b_obj + b_smp + 64;
+  if (need > sl.d_rec.cap) {  // (growing waits for the device: a compose of this slot may still read the old arena)
+    HIP_OK(c, hipDeviceSynchronize());
+    HIP_OK(c, sl.d_rec.reserve(need));
+  }
+  HIP_OK(c, sl.d_shapes.alias((DevShape*)sl.d_rec.p, n_shapes));
+  HIP_OK(c, sl.d_objects.alias((DevObject*)(sl.d_rec.p + b_shapes), n_obj));
+  HIP_OK(c, sl.d_samples.alias((DevSample*)(sl.d_rec.p + b_shapes + b_obj), (size_t)n_tasks));
   HIP_OK(c, sl.d_frames.reserve(n_shapes * 2));
   HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
   {
@@ -1162,11 +1186,6 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
       HIP_OK(c, hipDeviceSynchronize());
     }
   }
-  HIP_OK(c, sl.d_objects.reserve(n_obj));
-  HIP_OK(c, sl.d_samples.reserve(n_tasks));
-  const size_t b_shapes = n_shapes * sizeof(DevShape), b_obj = n_obj * sizeof(DevObject),
-               b_smp = (size_t)n_tasks * sizeof(DevSample);
-  const size_t need = b_shapes + b_obj + b_smp + 64;
   if (need > stage.bytes) {
     if (stage.h) HIP_OK(c, hipHostFree(stage.h));
     stage.h = nullptr;
@@ -1174,12 +1193,10 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     stage.bytes = need * 2;
   }
   char* hs = (char*)stage.h;
-  if (b_shapes) std::memcpy(hs, B.shapes.data(), b_shapes);
-  std::memcpy(hs + b_shapes, B.objects.data(), b_obj);
+  if (n_shapes) std::memcpy(hs, B.shapes.data(), n_shapes * sizeof(DevShape));
+  std::memcpy(hs + b_shapes, B.objects.data(), n_obj * sizeof(DevObject));
   std::memcpy(hs + b_shapes + b_obj, B.samples.data(), b_smp);
-  if (b_shapes) HIP_OK(c, hipMemcpyAsync(sl.d_shapes.p, hs, b_shapes, hipMemcpyHostToDevice, st));
-  HIP_OK(c, hipMemcpyAsync(sl.d_objects.p, hs + b_shapes, b_obj, hipMemcpyHostToDevice, st));
-  HIP_OK(c, hipMemcpyAsync(sl.d_samples.p, hs + b_shapes + b_obj, b_smp, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemcpyAsync(sl.d_rec.p, hs, b_shapes + b_obj + b_smp, hipMemcpyHostToDevice, st));
   if (!B.crops.empty()) {  // mode 9: this batch's crop table (+ upscaled background copies)
     const int W = c->prm.width, H = c->prm.height;
     const size_t crop_floats = (size_t)4 * (W + 1) * (H + 1), bg_floats = (size_t)4 * 2 * W * 2 * H;
@@ -1217,10 +1234,14 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   }
   HIP_OK(c, hipEventRecord(stage.free_ev, st));
   stage.pending = true;
-  if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
-  HIP_OK(c, hipEventRecord(sl.ev_uploaded, st));
-  sl.upload_pending = true;
-  sl.upload_stream = st;
+  if (shared) {
+    if (!sl.ev_uploaded) HIP_OK(c, hipEventCreateWithFlags(&sl.ev_uploaded, hipEventDisableTiming));
+    HIP_OK(c, hipEventRecord(sl.ev_uploaded, st));
+    sl.upload_pending = true;
+    sl.upload_stream = st;
+  } else {
+    sl.upload_pending = false;  // (a chain's private slot: uploaded and rendered in order on the chain's own stream)
+  }
   sl.res_samples = n_tasks;
   sl.res_shapes = (int)n_shapes;
   sl.res_objects = (int)n_obj;
@@ -1233,9 +1254,10 @@ int ofdg_render(ofdg_ctx* c, const ofdg_task* tasks, int n_tasks, const ofdg_blu
     if (c) c->err = "ofdg_render: invalid argument";
     return OFDG_EINVAL;
   }
+  stream = own_stream(c, stream);
   // the batch's records travel on the chain's own stream into its private slot
   ofdg_ctx::Chain& ch = take_chain(c);
-  int rc = upload_slot(c, ch.slot, tasks, n_tasks, bps, n_bps, chain_stream(c, ch, (hipStream_t)stream), ch.stage);
+  int rc = upload_slot(c, ch.slot, tasks, n_tasks, bps, n_bps, chain_stream(c, ch, (hipStream_t)stream), ch.stage, false);
   if (rc != OFDG_OK) return rc;
   return launch_resident(c, ch, ch.slot, d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
@@ -1246,18 +1268,20 @@ int ofdg_upload_slot(ofdg_ctx* c, int slot, const ofdg_task* tasks, int n_tasks,
     if (c) c->err = "ofdg_upload_slot: invalid argument";
     return OFDG_EINVAL;
   }
-  return upload_slot(c, c->slots[slot], tasks, n_tasks, bps, n_bps, (hipStream_t)stream, c->user_stage);
+  return upload_slot(c, c->slots[slot], tasks, n_tasks, bps, n_bps, (hipStream_t)stream, c->user_stage, true);
 }
 
 int ofdg_render_slot(ofdg_ctx* c, int slot, float* d_img0, float* d_img1, float* d_flow, void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || slot < 0 || slot >= ofdg_ctx::kUserSlots) return OFDG_EINVAL;
   if (c->slots[slot].res_samples <= 0) { c->err = "ofdg_render_slot: no batch is resident in this slot"; return OFDG_EINVAL; }
+  stream = own_stream(c, stream);
   return launch_resident(c, take_chain(c), c->slots[slot], d_img0, d_img1, d_flow, (hipStream_t)stream);
 }
 
 int ofdg_render_resident(ofdg_ctx* c, float* d_img0, float* d_img1, float* d_flow, void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow) return OFDG_EINVAL;
   if (!c->last_slot || c->last_slot->res_samples <= 0) { c->err = "ofdg_render_resident: nothing has been rendered yet"; return OFDG_EINVAL; }
+  stream = own_stream(c, stream);
   // a chain's private slot is not tracked by events while only that chain uses it: let its owner drain first
   for (int k = 0; k < c->n_chains; ++k)
     if (&c->chains[k].slot == c->last_slot && !c->last_slot->compose_pending) HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
@@ -1306,6 +1330,7 @@ static int prepare_counter_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n) {
 int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
                          void* stream) {
   if (!c || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
+  stream = own_stream(c, stream);
   // A sample is a pure function of (seed, global index): the chain samples, realises and prepares the batch on the device
   // and composes it, all in order on its stream.  Like the reference's prefetch thread (data_generation_layer.cpp:141-172)
   // the context runs AHEAD of its caller: after composing batch k it enqueues the preparation of the batches the caller's
@@ -1444,6 +1469,7 @@ int ofdg_set_step(ofdg_ctx* c, long long step) {
 
 int ofdg_synchronize(ofdg_ctx* c, void* stream) {
   if (!c) return OFDG_EINVAL;
+  if (stream == OFDG_STREAM_OWN) stream = nullptr;  // (every internal stream is waited for below)
   HIP_OK(c, hipStreamSynchronize((hipStream_t)stream));
   for (int k = 0; k < c->n_chains; ++k) {
     HIP_OK(c, hipStreamSynchronize(c->chains[k].stream));
@@ -1753,6 +1779,52 @@ int ofdg_debug_item_count(ofdg_ctx* c) {
   if (hipDeviceSynchronize() != hipSuccess) return OFDG_EHIP;
   if (hipMemcpy(&n, c->last_slot->d_item_count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return OFDG_EHIP;
   return n;
+}
+
+// ---- a step as ONE submission (inspection / experiment: tools/exp_graph.py) ----------------------------------
+// The kernels of one ofdg_forward_counter call - [counter sampler -> background preparation ->] geom -> raster -> compose -
+// captured from chain `chain`'s stream into a HIP graph with its parameters FROZEN (first_index, the output buffers, the
+// block-mask parity, the batch's error word), so that replays render the same batch again: enough to measure what the
+// submission form costs on the host and on the device with the real kernels, not a way to render new samples (the sampler's
+// first index, the mask parity and the error word change from step to step: a product graph would have to keep them in a
+// device-resident step record that every kernel reads at its start).
+int ofdg_debug_graph_capture(ofdg_ctx* c, int chain, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
+                             void** graph_exec) {
+  if (!c || !graph_exec || chain < 0 || chain >= c->n_chains || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
+  if (c->prm.sampler != OFDG_SAMPLER_COUNTER || !c->overlap || c->profiling) { c->err = "graph capture: counter sampler, chains and no profiling"; return OFDG_EINVAL; }
+  ofdg_ctx::Chain& ch = c->chains[chain];
+  HIP_OK(c, hipDeviceSynchronize());
+  { int rcd = discard_prepared(c, ch); if (rcd != OFDG_OK) return rcd; }
+  // every allocation happens before the capture starts (and once more, so that the tables of the preparation exist)
+  int rc = prepare_counter_slot(c, ch.slot, n_samples);
+  if (rc == OFDG_OK && c->prm.background_prep == 1) rc = ensure_bgprep_tables(c);
+  if (rc != OFDG_OK) return rc;
+  HIP_OK(c, hipDeviceSynchronize());
+  hipGraph_t g = nullptr;
+  HIP_OK(c, hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal));
+  rc = launch_prepare(c, ch, ch.slot, ch.stream, first_index, false);
+  if (rc == OFDG_OK) rc = launch_compose(c, ch, d_img0, d_img1, d_flow, ch.stream);
+  const hipError_t e = hipStreamEndCapture(ch.stream, &g);
+  // (the block-mask parity is frozen with the rest: capture TWO graphs per chain and replay them alternately - as bench.py's
+  //  two buffer sets per chain do - and each clears the masks the other marks, like consecutive launches)
+  if (rc != OFDG_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return OFDG_EHIP; }
+  hipGraphExec_t ge = nullptr;
+  HIP_OK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIP_OK(c, hipGraphDestroy(g));
+  *graph_exec = (void*)ge;
+  return OFDG_OK;
+}
+int ofdg_debug_graph_launch(ofdg_ctx* c, void* graph_exec, int chain) {
+  if (!c || !graph_exec || chain < 0 || chain >= c->n_chains) return OFDG_EINVAL;
+  HIP_OK(c, hipGraphLaunch((hipGraphExec_t)graph_exec, c->chains[chain].stream));
+  return OFDG_OK;
+}
+int ofdg_debug_graph_destroy(ofdg_ctx* c, void* graph_exec) {
+  if (!c || !graph_exec) return OFDG_EINVAL;
+  HIP_OK(c, hipDeviceSynchronize());
+  HIP_OK(c, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return OFDG_OK;
 }
 
 int ofdg_set_profiling(ofdg_ctx* c, int mode) {

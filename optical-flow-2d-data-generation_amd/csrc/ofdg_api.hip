@@ -1107,9 +1107,9 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
 #ifndef OFDG_FUSE_GRID
-#define OFDG_FUSE_GRID 512
+#define OFDG_FUSE_GRID 1024
 #endif
-  constexpr int kBgPrepFusedBlocks = OFDG_FUSE_GRID;  // two workgroups per CU walk the batch's tiles (320 .. 640: the same step rate; more crowd compose out)
+  constexpr int kBgPrepFusedBlocks = OFDG_FUSE_GRID;  // four workgroups per CU walk the batch's tiles (384: -3 %, 512 / 768: -2 %, profiles/r04_experiments_log.md)
   if (staged) {
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;

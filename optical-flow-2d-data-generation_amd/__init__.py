@@ -610,9 +610,9 @@ def _dptr(x):
 def alloc_outputs(n, height, width, device="cuda"):
     """The three top blobs: image0 [n,3,H,W], image1 [n,3,H,W], flow [n,2,H,W] (float32)."""
     import torch
-    return (torch.empty((n, 3, height, width), dtype=torch.float32, device=device),
-            torch.empty((n, 3, height, width), dtype=torch.float32, device=device),
-            torch.empty((n, 2, height, width), dtype=torch.float32, device=device))
+    return (torch.zeros((n, 3, height, width), dtype=torch.float32, device=device),
+            torch.zeros((n, 3, height, width), dtype=torch.float32, device=device),
+            torch.zeros((n, 2, height, width), dtype=torch.float32, device=device))
 
 
 class HostSampler:

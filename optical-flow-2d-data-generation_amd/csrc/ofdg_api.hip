@@ -856,7 +856,7 @@ static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes) {
 
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s, uint32_t* err);
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err);
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, uint32_t* err) {
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
@@ -867,7 +867,7 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
                      sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
   if (prep) {
-    int rc = prepare_backgrounds(c, sl, sl.res_samples, nullptr, s, err);
+    int rc = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, s, err);
     if (rc != OFDG_OK) return rc;
   }
   return OFDG_OK;
@@ -1098,11 +1098,11 @@ static int ensure_bgprep_tables(ofdg_ctx* c) {
   return OFDG_OK;
 }
 
-// background_prep: (upload the records of n samples and) render their 2W x 2H background
-// textures into the slot's buffer on stream `s` (bgprep_kernel)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const DevBgPrep* host_records, hipStream_t s, uint32_t* err) {
+// background_prep: render the 2W x 2H background textures of n samples into the slot's buffer on stream `s`; their
+// records are in sl.d_bgprep already (written by the device sampler, or uploaded with the batch's other records)
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err) {
   const int W = c->prm.width, H = c->prm.height;
-  HIP_OK(c, sl.d_bgprep.reserve(n));
+  if (!records_resident || !sl.d_bgprep.p || sl.d_bgprep.cap < (size_t)n) { c->err = "internal: background preparation without its records"; return OFDG_EINVAL; }
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
   int cap_cw, cap_ch;
   bool fusable;
@@ -1116,10 +1116,6 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, const Dev
   if (staged) {
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;
-  }
-  if (host_records) {
-    HIP_OK(c, hipMemcpyAsync(sl.d_bgprep.p, host_records, (size_t)n * sizeof(DevBgPrep), hipMemcpyHostToDevice, s));
-    HIP_OK(c, hipStreamSynchronize(s));  // (pageable source owned by the caller's batch)
   }
   if (!staged) {
     hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, W, H, sl.d_bgtex.p);
@@ -1167,8 +1163,9 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   // the batch's records - shapes | objects | samples - travel as ONE copy into one allocation (three copies cost the host
   // 7 us a batch, one 2.5: tools/microbench/launch_cost.hip - most of what a batch of one sample costs)
   const size_t b_shapes = (n_shapes * sizeof(DevShape) + 255) & ~(size_t)255, b_obj = (n_obj * sizeof(DevObject) + 255) & ~(size_t)255,
-               b_smp = (size_t)n_tasks * sizeof(DevSample);
-  const size_t need = b_shapes + b_obj + b_smp + 64;
+               b_smp = ((size_t)n_tasks * sizeof(DevSample) + 255) & ~(size_t)255,
+               b_prep = c->prm.background_prep ? B.bgprep.size() * sizeof(DevBgPrep) : 0;  // (the background preparation's records ride along)
+  const size_t need = b_shapes + b_obj + b_smp + b_prep + 64;
   if (need > sl.d_rec.cap) {  // (growing waits for the device: a compose of this slot may still read the old arena)
     HIP_OK(c, hipDeviceSynchronize());
     HIP_OK(c, sl.d_rec.reserve(need));
@@ -1176,6 +1173,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   HIP_OK(c, sl.d_shapes.alias((DevShape*)sl.d_rec.p, n_shapes));
   HIP_OK(c, sl.d_objects.alias((DevObject*)(sl.d_rec.p + b_shapes), n_obj));
   HIP_OK(c, sl.d_samples.alias((DevSample*)(sl.d_rec.p + b_shapes + b_obj), (size_t)n_tasks));
+  if (b_prep) HIP_OK(c, sl.d_bgprep.alias((DevBgPrep*)(sl.d_rec.p + b_shapes + b_obj + b_smp), B.bgprep.size()));
   HIP_OK(c, sl.d_frames.reserve(n_shapes * 2));
   HIP_OK(c, sl.d_verts.reserve(n_shapes * 2 * kMaxVerts));
   {
@@ -1198,8 +1196,9 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   char* hs = (char*)stage.h;
   if (n_shapes) std::memcpy(hs, B.shapes.data(), n_shapes * sizeof(DevShape));
   std::memcpy(hs + b_shapes, B.objects.data(), n_obj * sizeof(DevObject));
-  std::memcpy(hs + b_shapes + b_obj, B.samples.data(), b_smp);
-  HIP_OK(c, hipMemcpyAsync(sl.d_rec.p, hs, b_shapes + b_obj + b_smp, hipMemcpyHostToDevice, st));
+  std::memcpy(hs + b_shapes + b_obj, B.samples.data(), (size_t)n_tasks * sizeof(DevSample));
+  if (b_prep) std::memcpy(hs + b_shapes + b_obj + b_smp, B.bgprep.data(), b_prep);
+  HIP_OK(c, hipMemcpyAsync(sl.d_rec.p, hs, b_shapes + b_obj + b_smp + b_prep, hipMemcpyHostToDevice, st));
   if (!B.crops.empty()) {  // mode 9: this batch's crop table (+ upscaled background copies)
     const int W = c->prm.width, H = c->prm.height;
     const size_t crop_floats = (size_t)4 * (W + 1) * (H + 1), bg_floats = (size_t)4 * 2 * W * 2 * H;
@@ -1232,7 +1231,7 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     HIP_OK(c, hipStreamSynchronize(st));  // `tab` is a stack vector
   }
   if (c->prm.background_prep) {
-    int rcb = prepare_backgrounds(c, sl, n_tasks, B.bgprep.data(), st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
+    int rcb = prepare_backgrounds(c, sl, n_tasks, /*records_resident=*/true, st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
     if (rcb != OFDG_OK) return rcb;
   }
   HIP_OK(c, hipEventRecord(stage.free_ev, st));

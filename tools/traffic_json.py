@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json entries from the PMC passes of tools/profile_round.sh:
+   tools/traffic_json.py <round tag> <dir with pmc_{fetch,write}_size_config<C>_background_prep_<P>.txt> -> updates profiles/traffic.json
+HBM bytes per launch of the compose kernel = FETCH_SIZE (KB) x 2 (gfx950: a wide coalesced read is tallied at half,
+MI355X_MICROARCH.md) + WRITE_SIZE (KB)."""
+import glob, json, os, re, sys
+tag, d = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(root, "profiles", "traffic.json")
+tj = json.load(open(path)) if os.path.exists(path) else {}
+WORK = {2: "mode 5, 512x384, batch 32, 16 objects", 3: "mode 9, 512x384, batch 32, 16 objects", 4: "mode 7, 1024x768, batch 8, 32 objects",
+        5: "mode 7, 512x384, batch 32, 10000 x 1 MP pool"}
+
+
+def kernel_value(f, counter):
+    name, out = None, {}
+    for line in open(f):
+        if not line.startswith(" "):
+            name = line.split()[0]
+        elif name and "compose" in name:
+            k, v = line.split()
+            out[k] = float(v)
+            out["kernel"] = name.replace("ofdg::", "")
+    return out
+
+
+for f in sorted(glob.glob(os.path.join(d, "pmc_fetch_size_config*_background_prep_*.txt"))):
+    m = re.search(r"config(\d)_background_prep_(\d)", f)
+    cfg, bgp = int(m.group(1)), int(m.group(2))
+    fe, wr = kernel_value(f, "FETCH_SIZE"), kernel_value(f.replace("fetch", "write"), "WRITE_SIZE")
+    fetch2, write = int(fe["FETCH_SIZE"] * 1024 * 2), int(wr["WRITE_SIZE"] * 1024)
+    W, H, B = (1024, 768, 8) if cfg == 4 else (512, 384, 32)
+    tj["config%d_background_prep_%d" % (cfg, bgp)] = {
+        "kernel": fe["kernel"], "background_prep": bgp, "workload": "bench.py --config %d --background-prep %d (%s)" % (cfg, bgp, WORK[cfg]),
+        "fetch_size_kb_raw": fe["FETCH_SIZE"], "write_size_kb_raw": wr["WRITE_SIZE"], "fetch_bytes_corrected_x2": fetch2, "write_bytes": write,
+        "hbm_bytes_per_launch": fetch2 + write, "algorithmic_bytes_per_launch": 38 * W * H * B, "kernel_us_serialised": fe["dur_us"],
+        "source": "committed PMC passes profiles/%s_pmc_fetch_write_size_config%d_background_prep_%d.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                  "runs of bench.py, tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note; counter collection serialises the kernels)" % (tag, cfg, bgp)}
+    with open(os.path.join(root, "profiles", "%s_pmc_fetch_write_size_config%d_background_prep_%d.txt" % (tag, cfg, bgp)), "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE (first block) and --pmc WRITE_SIZE (second block), separate passes over bench.py --config %d --background-prep %d "
+                "--steps 60; per kernel: average of the counter (KB) and of the duration (us; kernels serialised by the collection)\n" % (cfg, bgp))
+        o.write(open(f).read() + "\n" + open(f.replace("fetch", "write")).read())
+json.dump(tj, open(path, "w"), indent=1)
+print("\n".join("%s: %.1f MB per launch (%.3f x algorithmic)" % (k, v["hbm_bytes_per_launch"] / 1e6, v["hbm_bytes_per_launch"] / v["algorithmic_bytes_per_launch"]) for k, v in tj.items()))

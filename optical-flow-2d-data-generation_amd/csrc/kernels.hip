@@ -1974,14 +1974,51 @@ __device__ __forceinline__ void fuse_finish_tile(const DevBgPrep& p, FuseTile& F
   }
   F.inside = __builtin_amdgcn_readfirstlane(inside ? 1 : 0);  // (wave-uniform by construction)
 }
-// one axis of CImg's linear get_resize with the destination pixel's table entry (a0 = at[k], al = alpha[k]) already in hand:
-// cimg_resize_texel without its two loads
+// ---- the resize passes in exact INTEGER arithmetic --------------------------------------------------------------------------
+// Enlarging: CImg evaluates (T)((1 - a) v1 + a v2) in double.  Where the weight a has at most 45 fractional bits - every
+// table entry whose source position is >= 128: the weight is `curr - floor(curr)` of a double `curr`, which then has at most
+// 52 - 7 fractional bits - 1 - a is exact, both products (8-bit integer x 45 fractional bits: 53 bits) are exact and so is
+// their sum (below 256): the double result IS the real number v1 + a (v2 - v1), and its truncation is
+//     v1 + floor(d A / 2^45),  d = v2 - v1,  A = a 2^45 = A1 2^23 + A0:
+//     d A = (d A1 + floor(d A0 / 2^23)) 2^23 + r,  0 <= r < 2^23   =>   floor(d A / 2^45) = (d A1 + (d A0 >> 23)) >> 22
+// (arithmetic shifts; |d A0| < 2^31, |d A1| < 2^30): two 24-bit multiplies, two shifts, two additions per channel instead of
+// two conversions, two fp64 products, an fp64 sum and a conversion.  Entries that are not exact keep the double form.
+// Shrinking: CImg's float moving average sum(v_j w_j) / n, truncated.  The sum is an integer below 2^24 (weights are overlap
+// lengths, sum n <= 4/3 of 1024..2048): exact in float; the correctly rounded quotient of an integer by n < 2^13 cannot round
+// up to the next integer (it is at least 1 / n below it, half an ulp at 255 is 2^-17): the byte is floor(sum / n), in integers
+// sum via v_mad_u32_u24 and the division by a multiply-high with M = ceil(2^32 / n) (exact for sum < 2^19 n / ... : the
+// error sum e / 2^32 < 2^-13 < 1 / n).
+struct FixWeight { int a1, a0; bool exact; };
+__device__ __forceinline__ FixWeight fix_weight(double al) {
+  const double t = ldexp(al, 45);           // (exact: a power of two)
+  const double u = floor(ldexp(t, -23));    // floor(a 2^22)
+  FixWeight w;
+  w.exact = al >= 0.0 && al < 1.0 && t == floor(t);
+  w.a1 = (int)u;
+  w.a0 = (int)(t - ldexp(u, 23));           // (exact when w.exact; unused otherwise)
+  return w;
+}
+__device__ __forceinline__ uint32_t enlarge_texel_fix(uint32_t t1, uint32_t t2, int a1, int a0) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int v1 = (int)((t1 >> (8 * c)) & 255u), d = (int)((t2 >> (8 * c)) & 255u) - v1;
+    const int m = (__mul24(d, a1) + (__mul24(d, a0) >> 23)) >> 22;
+    out |= (uint32_t)(v1 + m) << (8 * c);
+  }
+  return out;
+}
+// one axis of CImg's linear get_resize with the destination pixel's table entry (a0 = at[k], al = alpha[k]) already in hand
+// (cimg_resize_texel without its two loads); fw: the entry's weight in fixed point, fast: every lane's entry is exact (uniform);
+// mdiv = ceil(2^32 / n)
 template <class Texel>
-__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, Texel texel) {
+__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, const FixWeight& fw, bool fast, uint32_t mdiv,
+                                                          Texel texel) {
   if (sdim > n) {
+    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
+    if (fast) return enlarge_texel_fix(t1, t2, fw.a1, fw.a0);
     uint32_t out = 0;
     const double al1 = 1 - al;
-    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double v1 = u32_to_double((t1 >> (8 * c)) & 255u), v2 = u32_to_double((t2 >> (8 * c)) & 255u);
@@ -1989,12 +2026,24 @@ __device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k
     }
     return out;
   }
-  return cimg_resize_texel(n, sdim, k, (const uint16_t*)nullptr, (const double*)nullptr, texel);  // (same length / shrinking: no table)
+  if (sdim == n) return texel(k);
+  uint32_t acc[3] = {0u, 0u, 0u};
+  const int lo = k * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
+  for (int j = lo / sdim; j * sdim < hi; ++j) {
+    const int a = j * sdim, b = a + sdim;
+    const uint32_t d = (uint32_t)((b < hi ? b : hi) - (a > lo ? a : lo));
+    const uint32_t t = texel(j);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = __umul24((t >> (8 * c)) & 255u, d) + acc[c];
+  }
+  return __umulhi(acc[0], mdiv) | (__umulhi(acc[1], mdiv) << 8) | (__umulhi(acc[2], mdiv) << 16);
 }
 #ifdef OFDG_FUSE_STAMPS
 // experiment builds: wall-clock ticks (10 ns) per pass, summed over the tiles of thread 0 of every workgroup; [7] = tiles
 __device__ unsigned long long g_fuse_stamps[8];
-#define FUSE_STAMP(i) do { if (tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_fuse_stamps[i], (unsigned long long)(now_ - stamp_)); stamp_ = now_; } } while (0)
+// (summed in registers, flushed once when the workgroup is done: an atomic per stamp would sit in the same in-order memory
+//  counter as the loads the kernel waits for)
+#define FUSE_STAMP(i) do { const long long now_ = wall_clock64(); acc_[i] += (unsigned)(now_ - stamp_); stamp_ = now_; } while (0)
 #else
 #define FUSE_STAMP(i) do { } while (0)
 #endif
@@ -2007,6 +2056,7 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef OFDG_FUSE_STAMPS
   long long stamp_ = wall_clock64();
+  unsigned acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   // ---- the tiles of all samples are numbered consecutively: prefix of their counts (wave 0, 64 samples at a time) ----
   if (wave == 0) {
@@ -2129,9 +2179,12 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
     ey0 = __builtin_amdgcn_readfirstlane(vy0); ey1 = __builtin_amdgcn_readfirstlane(vy1);
     if (cur.fits) {
       // ---- X pass: M(x, j) over C(., j), in place: wave w takes rows w, w + 4, ...; lane = column of the tile ----
+      const FixWeight xw = fix_weight(xal);
+      const bool xfast = __ballot(x <= bx1 && !xw.exact) == 0ull;  // (the wave's columns all have exact weights: uniform)
+      const uint32_t xdiv = 0xFFFFFFFFu / (uint32_t)p.cw + 1u;
       for (int jj = wave; jj < nch; jj += kFuseWaves) {
         uint32_t m = 0;
-        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, [&](int i) { return s_c[jj][i - cx0]; });
+        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, xw, xfast, xdiv, [&](int i) { return s_c[jj][i - cx0]; });
         __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
         if (x <= bx1) s_c[jj][lane] = m;
       }
@@ -2141,21 +2194,28 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
     if (cur.fits && x <= bx1) {
       // ---- Y pass: B(x, y) over M(x, .): wave w takes rows kFuseRows w .. of the tile ----
       uint32_t* Bs = B + (size_t)cur.s * TW * TH;
+      const FixWeight ywv = fix_weight(yalv);  // (lane r: row r's weight)
+      const uint32_t ydiv = 0xFFFFFFFFu / (uint32_t)p.ch + 1u;
 #pragma unroll
       for (int r = 0; r < kFuseRows; ++r) {
         const int y = by0 + wave * kFuseRows + r;
         const int ya0 = __builtin_amdgcn_readlane(ya0v, r);  // (lane r holds row r's entry)
         const double yal = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yalv), r), __builtin_amdgcn_readlane(__double2loint(yalv), r));
-        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, [&](int j) { return s_c[j - cy0][lane]; });
+        FixWeight yw;
+        yw.a1 = __builtin_amdgcn_readlane(ywv.a1, r); yw.a0 = __builtin_amdgcn_readlane(ywv.a0, r);
+        yw.exact = __builtin_amdgcn_readlane((int)ywv.exact, r) != 0;
+        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, yw, yw.exact, ydiv, [&](int j) { return s_c[j - cy0][lane]; });
       }
     }
     FUSE_STAMP(4);
+#ifdef OFDG_FUSE_STAMPS
+    acc_[7] += 1;
+    if (!more && tid == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_fuse_stamps[i], (unsigned long long)acc_[i]);
+#endif
     if (!more) break;
     __syncthreads();  // (the next tile overwrites the rows)
     FUSE_STAMP(5);
-#ifdef OFDG_FUSE_STAMPS
-    if (tid == 0) atomicAdd(&g_fuse_stamps[7], 1ull);
-#endif
     cur = nxt;
     t = tn;
   }

@@ -332,6 +332,19 @@ def test_division_free_byte_quotient_is_the_correctly_rounded_one():
     assert newton == [] and len(mul) > 0
 
 
+def test_integer_forms_of_the_resize_passes_equal_the_reference_arithmetic():
+    """kernels.hip fix_weight / enlarge_texel_fix and the moving-average branch of cimg_resize_texel_pre replace CImg's
+    double interpolation (enlarging) and float moving average (shrinking) by integer arithmetic: equal for every byte pair
+    and every weight with at most 45 fractional bits (all table entries at source positions >= 128; the others are told
+    apart and keep the double form), and at every sum next to a multiple of the divisor (DG:87-109, CImg get_resize)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_resize_fix", os.path.join(os.path.dirname(__file__), "..", "tools", "check_resize_fix.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check_enlarging(np.random.default_rng(1)) > 4000
+    assert mod.check_shrinking() < 2 ** 24
+
+
 # ---- the sampler's statistics against what the REFERENCE's own sampler produced (BASELINE.md section 2) ----
 # Measured during the survey with the reference's ObjectParametersGenerator (DataGenerator.cpp:1358-2835, compiled
 # unmodified), 20 000 samples per mode: top-level objects, rasterised shapes, polygon vertices and curve3 segments per

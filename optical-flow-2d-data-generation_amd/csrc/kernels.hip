@@ -45,6 +45,12 @@ __device__ __forceinline__ long long floordiv64(long long a, long long b) {
 // --------------------------------------------------------------------------
 // wave-level helpers (wave64)
 // --------------------------------------------------------------------------
+// Issue priority.  Every kernel of a step but the background preparation raises its waves' priority: sampler, geom and raster
+// are latency-bound (a few hundred waves that gate their chain), compose is memory-bound (few instructions, long waits) - what
+// they can issue should go out at once - while the ALU-bound preparation of the OTHER chains fills the issue slots they leave.
+// +2.3 % on the headline step, +2.1 % with the composite objects of config 5 (priority for compose alone: +2.9 % / -0.7 .. -3 %;
+// profiles/r04_experiments_log.md section 10).  Without the preparation every wave has the same priority and nothing changes.
+__device__ __forceinline__ void step_kernel_priority() { __builtin_amdgcn_s_setprio(3); }
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
                                                    const DevCropRef* __restrict__ crops) {
   __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
   __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
+  step_kernel_priority();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
   if (sf >= n_shapes * 2) return;  // wave-uniform
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShap
                                                      unsigned long long* __restrict__ blockmask_next, int n_mask_words,
                                                      unsigned long long* __restrict__ blockmask) {
   __shared__ __attribute__((aligned(16))) RasterWs s_ws[kRasterWaves];
+  step_kernel_priority();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // clear the block masks the NEXT launch of this slot accumulates into (the other parity)
   for (int gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_mask_words; gid += gridDim.x * blockDim.x) blockmask_next[gid] = 0ull;
@@ -1052,6 +1060,7 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
                                               const DevShapeFrame* __restrict__ frames, int* __restrict__ item_count,
                                               const DevCropRef* __restrict__ crops = nullptr) {
   static_assert(kPx == 4, "mask bytes are packed four to a word");
+  step_kernel_priority();
   if (blockIdx.x == 0 && threadIdx.x == 0) *item_count = 0;  // raster_kernel has consumed the work list
   // XCD-aware strip mapping: blocks b and b + 8 share an XCD (round-robin dispatch).  Every XCD takes every 8th run of 32
   // consecutive strips (= one 64 x 16 tile row of 8 tiles): neighbouring strips share their background rows, coverage and

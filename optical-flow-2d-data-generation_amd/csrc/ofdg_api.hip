@@ -94,6 +94,7 @@ struct ofdg_ctx {
     DevBuf<uint32_t> d_bgC;
     DevBuf<unsigned long long> d_blockmask;  // [2 parities][samples][64 x 8 blocks][2 frames]
     int res_objects = 0;
+    bool bgprep_pending = false;  // background_prep: the records are in d_bgprep, the textures are rendered by the next launch_prepare
     int box_parity = 0;
     size_t box_stride = 0;   // mask words per parity
     int mask_used[2] = {0, 0};  // words the last launch on each parity marked (what the next clear must cover)
@@ -856,7 +857,7 @@ static int reserve_workspaces(ofdg_ctx* c, size_t n_shapes) {
 
 // ---- render -------------------------------------------------------------------------------
 // device counter sampler + device realize fill the slot's records (no host data)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err);
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err, hipEvent_t stop = nullptr);
 static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long first_index, hipStream_t s, uint32_t* err) {
   const int stride = sl.res_shapes / sl.res_samples;
   const int prep = c->prm.background_prep ? 1 : 0;
@@ -866,10 +867,7 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
   hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
                      sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());
-  if (prep) {
-    int rc = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, s, err);
-    if (rc != OFDG_OK) return rc;
-  }
+  sl.bgprep_pending = prep != 0;  // (rendered behind raster: launch_prepare)
   return OFDG_OK;
 }
 
@@ -958,6 +956,13 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
     int rc = launch_counter_sampler(c, sl, cs_first_index, S, err);
     if (rc != OFDG_OK) return rc;
   }
+  // The background preparation of the batch: LAST, right in front of compose (below) - except in mode 9, whose compose kernel
+  // is ALU-heavy itself (there the preparation goes first: 243 k against 235 k samples/s; profiles/r04_experiments_log.md section 11)
+  if (sl.bgprep_pending && c->prm.mode == 9) {
+    int rcb = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, S, err);
+    if (rcb != OFDG_OK) return rcb;
+    sl.bgprep_pending = false;
+  }
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
   sl.box_parity ^= 1;
@@ -975,11 +980,22 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
                         prof_prep ? ev[0] : nullptr, prof_prep ? ev[1] : nullptr, 0, sl.d_shapes.p, sl.res_shapes, c->d_cs_tab, W, H,
                         sl.d_frames.p, sl.d_verts.p, box_cur, err, sl.d_item_count, sl.d_items.p, croptab);
   HIP_OK(c, hipGetLastError());
-  // (a compose on a caller's stream takes the prepared batch over with the event on raster's own packet)
+  // The batch's last preparation kernel - raster, or the background preparation behind it - carries two things on its own
+  // packet: the hand-over event of a compose on a caller's stream, or (profiling 1) the start of the compose launch's time.
+  // The ALU-bound background preparation runs LAST, right in front of compose: sampler -> geom -> raster -> preparation ->
+  // compose is 4 % faster in the steady state than with the preparation behind the sampler (the latency-bound kernels of a
+  // chain follow each other, the two heavy ones too; profiles/r04_experiments_log.md section 11).
+  const bool prep_last = sl.bgprep_pending;
+  hipEvent_t last_stop = ev ? (c->profiling == 2 ? nullptr : ev[4]) : (hand_over ? ch.ev_prep : nullptr);
   hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
-                        ev ? ev[3] : (hand_over ? ch.ev_prep : nullptr), 0,
+                        (ev && c->profiling == 2) ? ev[3] : (prep_last ? nullptr : last_stop), 0,
                         sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words, box_cur);
   HIP_OK(c, hipGetLastError());
+  if (prep_last) {
+    int rcb = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, S, err, last_stop);
+    if (rcb != OFDG_OK) return rcb;
+    sl.bgprep_pending = false;
+  }
   if (ev && hand_over) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
   ch.prep.valid = true; ch.prep.slot = &sl; ch.prep.first_index = cs_first_index; ch.prep.n = sl.res_samples;
   ch.prep.box_cur = box_cur; ch.prep.croptab = croptab; ch.prep.ev = ev; ch.prep.stream = S; ch.prep.ticket = ticket;
@@ -1020,8 +1036,9 @@ static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float
   hipEvent_t done = (foreign || shared_slot) ? ch.ev_done : nullptr;
   // (profiled launches: start and stop are the timestamps of the compose kernel's own dispatch packet)
   // profiling 1 (compose only, what bench.py runs the timed region with): NO start marker - the compose launch is timed from
-  // the completion of its predecessor on the chain (raster's own packet, ev[3]) to its own completion: its dispatch gap
-  // (1 - 2 us) is counted with it, and nothing is added to the stream.  profiling 2: the kernel's own start and end.
+  // the completion of its predecessor on the chain (the last preparation kernel's own packet, ev[4], launch_prepare) to its
+  // own completion: its dispatch gap (1 - 2 us) is counted with it, and nothing is added to the stream.  profiling 2: the
+  // kernel's own start (a marker, ev[4]) and end.
   hipEvent_t k_start = (ev && c->profiling == 2) ? ev[4] : nullptr, k_stop = ev ? ev[5] : done;
   if (c->prm.mode == 9 && (W & (W - 1)) == 0)
     hipExtLaunchKernelGGL(compose_deform_pow2_kernel, dim3(compose_grid), dim3(64), 0, CS, k_start, k_stop, 0, dm, sl.d_samples.p,
@@ -1100,7 +1117,8 @@ static int ensure_bgprep_tables(ofdg_ctx* c) {
 
 // background_prep: render the 2W x 2H background textures of n samples into the slot's buffer on stream `s`; their
 // records are in sl.d_bgprep already (written by the device sampler, or uploaded with the batch's other records)
-static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err) {
+//   stop: an event for the completion of the LAST kernel launched here (on that kernel's own packet)
+static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool records_resident, hipStream_t s, uint32_t* err, hipEvent_t stop) {
   const int W = c->prm.width, H = c->prm.height;
   if (!records_resident || !sl.d_bgprep.p || sl.d_bgprep.cap < (size_t)n) { c->err = "internal: background preparation without its records"; return OFDG_EINVAL; }
   HIP_OK(c, sl.d_bgtex.reserve((size_t)n * 4 * W * H));
@@ -1118,21 +1136,21 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
     if (rct != OFDG_OK) return rct;
   }
   if (!staged) {
-    hipLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, sl.d_bgprep.p, W, H, sl.d_bgtex.p);
+    hipExtLaunchKernelGGL(bgprep_kernel, dim3((W * H + 255) / 256, n), dim3(256), 0, s, nullptr, stop, 0, sl.d_bgprep.p, W, H, sl.d_bgtex.p);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
   if (fusable && n <= kFuseMaxSamples) {
-    hipLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), 0, s, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
+    hipExtLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), 0, s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
   HIP_OK(c, sl.d_bgC.reserve((size_t)n * cap_cw * cap_ch));
   hipLaunchKernelGGL(bgprep_rotcrop_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
                      err);
-  hipLaunchKernelGGL(bgprep_resize_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
-                     sl.d_bgtex.p);
+  hipExtLaunchKernelGGL(bgprep_resize_kernel, dim3(kBgPrepBlocks, n), dim3(256), 0, s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, cap_cw, cap_ch, sl.d_bgC.p,
+                        sl.d_bgtex.p);
   HIP_OK(c, hipGetLastError());
   return OFDG_OK;
 }
@@ -1231,8 +1249,13 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
     HIP_OK(c, hipStreamSynchronize(st));  // `tab` is a stack vector
   }
   if (c->prm.background_prep) {
-    int rcb = prepare_backgrounds(c, sl, n_tasks, /*records_resident=*/true, st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
-    if (rcb != OFDG_OK) return rcb;
+    if (shared) {  // a caller's slot is prepared once, here, and rendered any number of times
+      int rcb = prepare_backgrounds(c, sl, n_tasks, /*records_resident=*/true, st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
+      if (rcb != OFDG_OK) return rcb;
+      sl.bgprep_pending = false;
+    } else {
+      sl.bgprep_pending = true;  // (a chain's private slot: behind raster, launch_prepare)
+    }
   }
   HIP_OK(c, hipEventRecord(stage.free_ev, st));
   stage.pending = true;
@@ -1869,9 +1892,9 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
     hipEvent_t* ev = &c->ev[(size_t)k * 6];
     HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
-    // geom: its own start .. its end; raster: end of geom .. its end; compose: its own start (profiling 2) or the end of raster
-    // (profiling 1) .. its end
-    HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : (i == 2 ? (c->profiling == 2 ? 4 : 3) : 1)], ev[2 * i + 1]));
+    // geom: its own start .. its end; raster: end of geom .. its end; compose: its own start (profiling 2) or the end of the
+    // last preparation kernel (profiling 1) .. its end
+    HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : (i == 2 ? 4 : 1)], ev[2 * i + 1]));
     acc += t;
   }
   if (n == 0) { c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)"; return OFDG_EINVAL; }

@@ -1035,3 +1035,29 @@ def test_device_error_is_reported_at_its_own_batch(ofdg, oracle):
     with pytest.raises(ofdg.OfdgError) as e:
         g.synchronize()
     assert e.value.code == ofdg.ECAPACITY
+
+
+def test_background_prep_batches_beyond_one_wave_of_samples(ofdg, oracle):
+    """bgprep_fused_kernel numbers the tiles of all samples through a prefix of their tile counts that wave 0 builds 64 samples
+    at a time: a batch of 150 samples (three rounds of the prefix, tiles of late samples reached by grid-stride) renders like
+    the oracle, through the host-sampled path (records uploaded with the batch, the preparation behind raster) and through
+    the device sampler."""
+    W, H, B = 64, 48, 150
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1, sampler=1, seed=31, num_objects=3)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(4, 160, 120, 3)
+    host_pool = g.pool_download_all()
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    tasks, bps, n = oracle.Sampler(5, W, H, 3).next(B)
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0) and np.array_equal(got[1], e1) and ulp_diff(got[2], ef).max() == 0
+    i0, i1, fl = ofdg.alloc_outputs(B, H, W)
+    g.forward_counter(1000, B, i0, i1, fl, ofdg.STREAM_OWN)
+    g.synchronize()
+    tasks, bps, n = g.sample_counter(1000, B)
+    with oracle.detmath():
+        e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(i0.cpu().numpy(), e0) and np.array_equal(i1.cpu().numpy(), e1)
+    assert ulp_diff(fl.cpu().numpy(), ef).max() == 0

@@ -330,6 +330,7 @@ def timed_pass(ofdg, gen, cfg, pl, outs, steps, warmup, rank, world, stream):
     import torch
     BATCH, NBUF = cfg["batch"], len(outs)
     host_sampler_rate = None
+    outs = [ofdg.device_pointers(o) for o in outs]  # (the buffer sets' device addresses, resolved once)
     if cfg["sampler"] in ("counter", "ref"):
         def step(i):  # counter: samples (step*world + rank)*B + [0, B) on the device, then renders; ref (config 1): the
             gen.forward(*outs[i % NBUF], ofdg.STREAM_OWN)  # reference-stream sampler on the host inside the step, like load_batch

@@ -234,17 +234,16 @@ __device__ __forceinline__ int outline_verts(const DevShape& S, const Mat& M, co
   return n_verts;
 }
 
-__global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
-                                                   const double* __restrict__ cs_tab, int W, int H,
-                                                   DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
-                                                   unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
-                                                   int* __restrict__ item_count, int4* __restrict__ items,
-                                                   const DevCropRef* __restrict__ crops) {
-  __shared__ double s_stack[kGeomWaves][kCurveSlots][kCurveMaxDepth][5];
-  __shared__ int2 s_stage[kGeomWaves][kCurveSlots][kCurveMaxPts];
-  step_kernel_priority();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
+// LDS of one geom wave: the curve3 stacks and the staging of their points
+struct GeomWs {
+  double stack[kCurveSlots][kCurveMaxDepth][5];
+  int2 stage[kCurveSlots][kCurveMaxPts];
+};
+// one wave = one (outline, frame) sf
+__device__ __forceinline__ void geom_wave(GeomWs& ws, int sf, int lane, const DevShape* __restrict__ shapes, int n_shapes,
+                                          const double* __restrict__ cs_tab, int W, int H, DevShapeFrame* __restrict__ frames,
+                                          int2* __restrict__ verts, unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
+                                          int* __restrict__ item_count, int4* __restrict__ items, const DevCropRef* __restrict__ crops) {
   if (sf >= n_shapes * 2) return;  // wave-uniform
   const DevShape& S = shapes[sf >> 1];
   if (S.type == 0) return;  // unused slot of a device-sampled batch (wave-uniform)
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
   int2* out = verts + (size_t)sf * kMaxVerts;
 
   int minx, miny, maxx, maxy;
-  int n_verts = outline_verts(S, M, cs_tab, out, s_stack[wave], s_stage[wave], err, lane, minx, miny, maxx, maxy);
+  int n_verts = outline_verts(S, M, cs_tab, out, ws.stack, ws.stage, err, lane, minx, miny, maxx, maxy);
   // AGG dx_limit: an edge spanning >= 16384 px takes a different code path in
   // rasterizer_cells_aa::line; blueprints never get close, flag it if one does.
   if (n_verts > 0 && ((long long)maxx - (long long)minx >= (16384LL << 8))) {
@@ -308,6 +307,19 @@ __global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* _
       items[base + i] = make_int4(sf, b, cx, min(cx + kChunkW - 1, xb));
     }
   }
+}
+
+__global__ __launch_bounds__(64 * kGeomWaves) void geom_kernel(const DevShape* __restrict__ shapes, int n_shapes,
+                                                   const double* __restrict__ cs_tab, int W, int H,
+                                                   DevShapeFrame* __restrict__ frames, int2* __restrict__ verts,
+                                                   unsigned long long* __restrict__ blockmask, uint32_t* __restrict__ err,
+                                                   int* __restrict__ item_count, int4* __restrict__ items,
+                                                   const DevCropRef* __restrict__ crops) {
+  __shared__ GeomWs s_ws[kGeomWaves];
+  step_kernel_priority();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sf = __builtin_amdgcn_readfirstlane(blockIdx.x * kGeomWaves + wave);
+  geom_wave(s_ws[wave], sf, lane, shapes, n_shapes, cs_tab, W, H, frames, verts, blockmask, err, item_count, items, crops);
 }
 
 // --------------------------------------------------------------------------

@@ -1968,7 +1968,7 @@ struct FuseTile {
   int fits;                 // ... which fit the LDS tile of C
   int inside;               // no mirroring / clamping anywhere in the tile: the per-texel range tests are skipped
 };
-__device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }
+__device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
 __device__ __forceinline__ int fuse_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kFuseW) / kFuseW; }
 // cimg_resize_range with the two table entries it reads already in hand (e0 = at[n * s + d0], e1 = at[n * s + d1])
 __device__ __forceinline__ void fuse_range(int n, int s, int d0, int d1, int e0, int e1, int* lo, int* hi) {
@@ -2029,12 +2029,39 @@ __device__ __forceinline__ uint32_t enlarge_texel_fix(uint32_t t1, uint32_t t2, 
   }
   return out;
 }
+// Shrinking by less than half (n <= 2 sdim: what a fused tile holds, fuse_sample_fits): destination texel k averages the source
+// interval [k n, (k + 1) n) in units of 1 / sdim, which touches at most THREE source texels j0, j0 + 1, j0 + 2 with overlap
+// lengths d0 > 0, d1, d2 >= 0 (sum n).  The taps depend on (n, sdim, k) only: once per column of a tile in the X pass, once
+// per row in the Y pass (scalar) - not per texel.
+struct ShrinkTaps { int j0; uint32_t d0, d1, d2; };
+__device__ __forceinline__ ShrinkTaps shrink_taps(int n, int sdim, int k) {
+  const int lo = k * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
+  ShrinkTaps t;
+  t.j0 = lo / sdim;
+  const int a = t.j0 * sdim;
+  t.d0 = (uint32_t)(min(a + sdim, hi) - lo);
+  t.d1 = (uint32_t)min(max(hi - (a + sdim), 0), sdim);
+  t.d2 = (uint32_t)min(max(hi - (a + 2 * sdim), 0), sdim);
+  return t;
+}
+// floor(acc / n) for acc <= 255 n as a multiply-high by mdiv = ceil(2^32 / n) = 2^32 / n + e, 0 <= e < 1: the product is
+// 2^32 (acc / n + acc e / 2^32), and the excess acc e / 2^32 < 255 n / 2^32 stays below the 1 / n that separates acc / n from the
+// next integer as long as 255 n^2 < 2^32: n <= 4103 (crops of frames up to 1536 wide).  With n > 256 both factors are also
+// below 2^24: the full-rate 24-bit multiply-high instead of the quarter-rate 32-bit one.  Any other n: 32-bit multiply-high
+// (one too large at most) and a correction.
+__device__ __forceinline__ bool shrink_div24(int n) { return n > 256 && n <= 4103; }
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // one axis of CImg's linear get_resize with the destination pixel's table entry (a0 = at[k], al = alpha[k]) already in hand
 // (cimg_resize_texel without its two loads); fw: the entry's weight in fixed point, fast: every lane's entry is exact (uniform);
-// mdiv = ceil(2^32 / n)
+// st: the taps of a shrinking axis, jmax: the last source index the tile holds (a tap of weight 0 beyond it is read from jmax),
+// mdiv = ceil(2^32 / n), div24: n > 256 (uniform)
 template <class Texel>
-__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, const FixWeight& fw, bool fast, uint32_t mdiv,
-                                                          Texel texel) {
+__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, const FixWeight& fw, bool fast, const ShrinkTaps& st,
+                                                          int jmax, uint32_t mdiv, bool div24, Texel texel) {
   if (sdim > n) {
     const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
     if (fast) return enlarge_texel_fix(t1, t2, fw.a1, fw.a0);
@@ -2048,16 +2075,20 @@ __device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k
     return out;
   }
   if (sdim == n) return texel(k);
-  uint32_t acc[3] = {0u, 0u, 0u};
-  const int lo = k * n, hi = lo + n;  // (< 2^31: both lengths are a few thousand at most)
-  for (int j = lo / sdim; j * sdim < hi; ++j) {
-    const int a = j * sdim, b = a + sdim;
-    const uint32_t d = (uint32_t)((b < hi ? b : hi) - (a > lo ? a : lo));
-    const uint32_t t = texel(j);
+  const uint32_t t0 = texel(st.j0), t1 = texel(min(st.j0 + 1, jmax)), t2 = texel(min(st.j0 + 2, jmax));
+  uint32_t acc[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) acc[c] = __umul24((t >> (8 * c)) & 255u, d) + acc[c];
+  for (int c = 0; c < 3; ++c)
+    acc[c] = __umul24((t2 >> (8 * c)) & 255u, st.d2) + (__umul24((t1 >> (8 * c)) & 255u, st.d1) + __umul24((t0 >> (8 * c)) & 255u, st.d0));
+  if (div24) return mulhi_u24(acc[0], mdiv) | (mulhi_u24(acc[1], mdiv) << 8) | (mulhi_u24(acc[2], mdiv) << 16);
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint32_t q = __umulhi(acc[c], mdiv);
+    q -= (q * (uint32_t)n > acc[c]) ? 1u : 0u;
+    out |= q << (8 * c);
   }
-  return __umulhi(acc[0], mdiv) | (__umulhi(acc[1], mdiv) << 8) | (__umulhi(acc[2], mdiv) << 16);
+  return out;
 }
 #ifdef OFDG_FUSE_STAMPS
 // experiment builds: wall-clock ticks (10 ns) per pass, summed over the tiles of thread 0 of every workgroup; [7] = tiles
@@ -2203,9 +2234,11 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       const FixWeight xw = fix_weight(xal);
       const bool xfast = __ballot(x <= bx1 && !xw.exact) == 0ull;  // (the wave's columns all have exact weights: uniform)
       const uint32_t xdiv = 0xFFFFFFFFu / (uint32_t)p.cw + 1u;
+      const bool xdiv24 = shrink_div24(p.cw);
+      const ShrinkTaps xs = shrink_taps(p.cw, TW, min(x, bx1));  // (this column's taps: the same in every row)
       for (int jj = wave; jj < nch; jj += kFuseWaves) {
         uint32_t m = 0;
-        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, xw, xfast, xdiv, [&](int i) { return s_c[jj][i - cx0]; });
+        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, xw, xfast, xs, cx1, xdiv, xdiv24, [&](int i) { return s_c[jj][i - cx0]; });
         __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
         if (x <= bx1) s_c[jj][lane] = m;
       }
@@ -2217,6 +2250,7 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       uint32_t* Bs = B + (size_t)cur.s * TW * TH;
       const FixWeight ywv = fix_weight(yalv);  // (lane r: row r's weight)
       const uint32_t ydiv = 0xFFFFFFFFu / (uint32_t)p.ch + 1u;
+      const bool ydiv24 = shrink_div24(p.ch);
 #pragma unroll
       for (int r = 0; r < kFuseRows; ++r) {
         const int y = by0 + wave * kFuseRows + r;
@@ -2225,7 +2259,8 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
         FixWeight yw;
         yw.a1 = __builtin_amdgcn_readlane(ywv.a1, r); yw.a0 = __builtin_amdgcn_readlane(ywv.a0, r);
         yw.exact = __builtin_amdgcn_readlane((int)ywv.exact, r) != 0;
-        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, yw, yw.exact, ydiv, [&](int j) { return s_c[j - cy0][lane]; });
+        const ShrinkTaps ys = shrink_taps(p.ch, TH, y);  // (uniform: scalar arithmetic)
+        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, yw, yw.exact, ys, cur.cy1, ydiv, ydiv24, [&](int j) { return s_c[j - cy0][lane]; });
       }
     }
     FUSE_STAMP(4);

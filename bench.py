@@ -71,6 +71,7 @@ POOL_SEED = 2024
 NSLOT = 12
 SEED = 20261003
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # G wave64 vector instructions/s: 256 CUs x 4 SIMD16 at 2.4 GHz, 4 cycles per wave64 instruction
 
 
 def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128, background_prep=0):
@@ -411,20 +412,23 @@ def main():
 
     compose_ms = gen.kernel_ms("compose")
     parts = alone = cpu_base = None
+    # the background preparation's launch is timed where it runs behind raster (every mode but 9; device-sampled batches)
+    names = ("geom", "raster", "compose") + (("background_prep",) if bgp and counter and cfg["mode"] != 9 else ())
+    prep_ms = gen.kernel_ms("background_prep") if "background_prep" in names else None
     if rank == 0:
         # second short pass with all three kernels timed (not part of `value`)
         gen.set_profiling(2)
         for i in range(min(args.steps, 48)):
             step(i)
         gen.synchronize(stream)
-        parts = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        parts = {k: gen.kernel_ms(k) for k in names}
         # third short pass, one batch at a time (device idle between the steps): the kernels' durations with nothing
         # else in flight - what one launch of the compose kernel takes when it has the GPU to itself
         gen.set_profiling(2)
         for i in range(min(args.steps, 32)):
             step(i)
             gen.synchronize(stream)
-        alone = {k: gen.kernel_ms(k) for k in ("geom", "raster", "compose")}
+        alone = {k: gen.kernel_ms(k) for k in names}
         gen.set_profiling(0)
         if world == 1 and not args.no_cpu_baseline:
             cpu_base = cpu_baseline(ofdg, gen, cfg, host_pool=args.cpu_pool, background_prep=1 if bgp else 0)
@@ -465,13 +469,14 @@ def main():
         kernel = ("compose_deform" if cfg["mode"] == 9 else "compose_rigid") + ("_pow2_kernel" if W & (W - 1) == 0 else "_kernel")
         # HBM bytes per launch of that kernel from the PMC passes committed for THIS configuration (tools/profile_round.sh:
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script); null when no pass of this config is committed
-        traffic, traffic_src = None, None
+        traffic, traffic_src, prep_pmc = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             ent = tj.get("config%d_background_prep_%d" % (args.config, bgp))
             if ent and ent.get("kernel") == kernel and ent.get("background_prep", 0) == bgp:
                 traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
+                prep_pmc = ent.get("background_prep_kernel")
         out = {
             "metric": "training samples/sec (img0+img1+flow, %dx%d)" % (W, H),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -509,6 +514,21 @@ def main():
             "kernel_ms": parts, "kernel_ms_alone": alone,
             "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
+        if prep_ms is not None:
+            # The step's other heavy kernel is bound by vector-instruction issue, not by HBM or MFMA: its
+            # launch against the chip's issue rate - 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz.
+            # Instruction counts per launch come from the committed PMC pass of this configuration (null without one).
+            valu = prep_pmc.get("valu_instructions_per_launch") if prep_pmc else None
+            out["background_prep_kernel"] = {
+                "kernel": (prep_pmc or {}).get("kernel", "bgprep_fused_kernel"), "bound": "vector instruction issue",
+                "kernel_ms": prep_ms, "kernel_ms_alone": alone["background_prep"],
+                "valu_instructions_per_launch": valu, "peak": VALU_PEAK_GINST, "unit": "G wave instructions/s",
+                "achieved": valu / (prep_ms * 1e-3) / 1e9 if valu else None,
+                "achieved_alone": valu / (alone["background_prep"] * 1e-3) / 1e9 if valu else None,
+                "frac_alone": valu / (alone["background_prep"] * 1e-3) / 1e9 / VALU_PEAK_GINST if valu else None,
+                "hbm_bytes_per_launch": (prep_pmc or {}).get("hbm_bytes_per_launch"),
+                "source": (prep_pmc or {}).get("source"),
+                "note": "runs at issue priority 0 beside the other chains' kernels (priority 3): in the pipeline its launch stretches over their gaps"}
         out["centre_crop_backgrounds" if bgp2 == 0 else "reference_equivalent"] = secondary
         if host_sampler_rate is not None:
             out["host_ref_sampler_samples_per_s"] = host_sampler_rate

@@ -314,8 +314,6 @@ int ofdg_debug_graph_capture(ofdg_ctx* ctx, int chain, long long first_index, in
                              float* d_image0, float* d_image1, float* d_flow, void** graph_exec);
 int ofdg_debug_graph_launch(ofdg_ctx* ctx, void* graph_exec, int chain);
 int ofdg_debug_graph_destroy(ofdg_ctx* ctx, void* graph_exec);
-/* Per-kernel device time (ms) of the last render, measured with HIP events on
- * the launch stream when profiling is enabled. names: "geom","raster","compose". */
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract
  * [u*256+v] (DG:606, 626), AA mask byte [c], draw_image blend [d*256+m] for s=s_fixed. */
 int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl,
@@ -324,7 +322,11 @@ int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t
  * on the device: n angles -> sin, cos; m floats -> expf.  Host arrays. */
 int ofdg_debug_detmath(ofdg_ctx* ctx, const double* angles, int n, double* sin_out, double* cos_out,
                        const float* x, int m, float* expf_out);
-int ofdg_set_profiling(ofdg_ctx* ctx, int enabled);
+/* Per-kernel device time (ms), averaged over the launches recorded since ofdg_set_profiling (mode 1: the compose launch
+ * and the background preparation of every 4th batch, completion signals on the kernels' own packets, nothing added to the
+ * streams; mode 2: every kernel of every batch, with start markers; 0: off).  Names: "geom", "raster" (mode 2), "compose",
+ * "background_prep" (where the preparation runs behind raster: every mode but 9, batches the library prepares itself). */
+int ofdg_set_profiling(ofdg_ctx* ctx, int mode);
 int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
 
 /* ---- host-side pieces (no HIP device needed) --------------------------------- */

@@ -202,6 +202,7 @@ struct ofdg_ctx {
   int ev_sets = 0, ev_stride = 1;
   long long ev_count = 0, ev_alloc = 0, launch_count = 0;  // event sets: composed / handed out (a prepared batch holds one)
   std::vector<char> ev_composed;  // per set: its compose was enqueued (a prepared batch that is discarded leaves its set incomplete)
+  std::vector<char> ev_bgprep;    // per set: the batch's background preparation ran behind raster and is timed (ev[3] .. ev[2] or ev[4])
   std::vector<ofdg_task> fw_tasks;
   std::vector<ofdg_blueprint> fw_bps;
 };
@@ -926,6 +927,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
     const size_t set = (size_t)(c->ev_alloc++ % c->ev_sets);
     ev = &c->ev[set * 6];
     c->ev_composed[set] = 0;
+    c->ev_bgprep[set] = 0;
   }
   c->launch_count++;
   if (!c->overlap) {
@@ -987,14 +989,16 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   // chain follow each other, the two heavy ones too; profiles/r04_experiments_log.md section 11).
   const bool prep_last = sl.bgprep_pending;
   hipEvent_t last_stop = ev ? (c->profiling == 2 ? nullptr : ev[4]) : (hand_over ? ch.ev_prep : nullptr);
+  // (a profiled batch with a preparation behind raster also takes raster's completion: the preparation is timed from there)
   hipExtLaunchKernelGGL(raster_kernel, dim3(kRasterGrid * 4 / kRasterWaves), dim3(64 * kRasterWaves), 0, S, nullptr,
-                        (ev && c->profiling == 2) ? ev[3] : (prep_last ? nullptr : last_stop), 0,
+                        (ev && (c->profiling == 2 || prep_last)) ? ev[3] : (prep_last ? nullptr : last_stop), 0,
                         sl.d_frames.p, sl.d_items.p, sl.d_item_count, sl.d_verts.p, W, H, cov, box_next, n_mask_words, box_cur);
   HIP_OK(c, hipGetLastError());
   if (prep_last) {
-    int rcb = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, S, err, last_stop);
+    int rcb = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, S, err, (ev && c->profiling == 2) ? ev[2] : last_stop);
     if (rcb != OFDG_OK) return rcb;
     sl.bgprep_pending = false;
+    if (ev) c->ev_bgprep[(size_t)(ev - c->ev.data()) / 6] = 1;
   }
   if (ev && hand_over) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
   ch.prep.valid = true; ch.prep.slot = &sl; ch.prep.first_index = cs_first_index; ch.prep.n = sl.res_samples;
@@ -1870,6 +1874,7 @@ int ofdg_set_profiling(ofdg_ctx* c, int mode) {
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
   }
   c->ev_composed.assign((size_t)c->ev_sets, 0);
+  c->ev_bgprep.assign((size_t)c->ev_sets, 0);
   return OFDG_OK;
 }
 
@@ -1882,6 +1887,7 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   if (!std::strcmp(kernel, "geom")) i = 0;
   else if (!std::strcmp(kernel, "raster")) i = 1;
   else if (!std::strcmp(kernel, "compose")) i = 2;
+  else if (!std::strcmp(kernel, "background_prep")) i = 3;  // (timed where it runs behind raster: not in mode 9, not for a caller's slot prepared at its upload)
   if (i < 0) { c->err = "unknown kernel name"; return OFDG_EINVAL; }
   if (!c->profiling || c->ev_count == 0 || (i < 2 && c->profiling != 2)) {
     c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)";
@@ -1891,10 +1897,16 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   double acc = 0;
   for (int k = 0; k < c->ev_sets; ++k) {
     if (!c->ev_composed[(size_t)k]) continue;  // (never handed out, or its prepared batch was discarded before compose)
+    if (i == 3 && !c->ev_bgprep[(size_t)k]) continue;
     ++n;
     hipEvent_t* ev = &c->ev[(size_t)k * 6];
     HIP_OK(c, hipEventSynchronize(ev[5]));
     float t = 0;
+    if (i == 3) {  // completion of raster .. completion of the (last) preparation kernel
+      HIP_OK(c, hipEventElapsedTime(&t, ev[3], ev[c->profiling == 2 ? 2 : 4]));
+      acc += t;
+      continue;
+    }
     // geom: its own start .. its end; raster: end of geom .. its end; compose: its own start (profiling 2) or the end of the
     // last preparation kernel (profiling 1) .. its end
     HIP_OK(c, hipEventElapsedTime(&t, ev[i == 0 ? 0 : (i == 2 ? 4 : 1)], ev[2 * i + 1]));

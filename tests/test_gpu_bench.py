@@ -51,6 +51,12 @@ def test_bench_line_carries_the_contract_fields():
     e = d["centre_crop_backgrounds"]
     assert e["background_prep"] == 0 and e["unit"] == "samples/s" and e["value"] > d["value"] > 0
     assert "reference_equivalent" not in d
+    # the step's other heavy kernel is reported beside the compose kernel's roofline: its launch in the pipeline and alone
+    k = d["background_prep_kernel"]
+    assert k["bound"] == "vector instruction issue" and k["peak"] == 256 * 4 * 2.4 / 4
+    assert k["kernel_ms"] > 0 and k["kernel_ms_alone"] > 0 and d["kernel_ms_alone"]["background_prep"] == k["kernel_ms_alone"]
+    if k["valu_instructions_per_launch"]:   # (a PMC pass of this configuration is committed)
+        assert abs(k["frac_alone"] - k["valu_instructions_per_launch"] / (k["kernel_ms_alone"] * 1e-3) / 1e9 / k["peak"]) < 1e-9
 
 
 @pytest.mark.gpu
@@ -68,3 +74,4 @@ def test_bench_centre_crop_headline_says_so():
     d = bench("--background-prep", "0", "--no-secondary")
     check_contract(d)
     assert d["config"]["background_prep"] == 0 and "CENTRE-CROP" in d["config"]["workload"]
+    assert "background_prep_kernel" not in d

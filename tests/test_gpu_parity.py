@@ -707,6 +707,29 @@ def test_background_prep_border_tiles(ofdg, oracle, zoom):
     assert ulp_diff(got[2], ef).max() == 0
 
 
+@pytest.mark.parametrize("zoom", [0.76, 0.8, 0.99])
+def test_background_prep_wide_frames_average_over_long_crops(ofdg, oracle, zoom):
+    """The moving average of a shrinking resize axis divides by the crop's length n with a multiply-high.  The 24-bit
+    form holds for 256 < n <= 4103 (255 n^2 < 2^32); longer crops (frames wider than 1536: n = 3200 / zoom) and short
+    ones (the 48 rows here) take the 32-bit form with its correction.  1600 x 24, bit-exact against the oracle's
+    true divisions."""
+    W, H, B = 1600, 24, 2
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(2, 3328, 64, 9)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    for t in tasks:
+        bps[t.background].tex_scale = zoom
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
+    assert ulp_diff(got[2], ef).max() == 0
+
+
 def test_background_prep_zoom_beyond_the_workspace_is_reported(ofdg, oracle):
     """background_prep = 1 keeps workspaces for crops of the rotated image up to zoom 0.75 (the sampler draws
     0.8 .. 1.2).  A caller's blueprint with a smaller zoom must not be rendered wrongly in silence: the device flags

@@ -12,12 +12,12 @@ WORK = {2: "mode 5, 512x384, batch 32, 16 objects", 3: "mode 9, 512x384, batch 3
         5: "mode 7, 512x384, batch 32, 10000 x 1 MP pool"}
 
 
-def kernel_value(f, counter):
+def kernel_value(f, counter, which="compose"):
     name, out = None, {}
     for line in open(f):
         if not line.startswith(" "):
             name = line.split()[0]
-        elif name and "compose" in name:
+        elif name and which in name:
             k, v = line.split()
             out[k] = float(v)
             out["kernel"] = name.replace("ofdg::", "")
@@ -36,6 +36,22 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_fetch_size_config*_background_pre
         "hbm_bytes_per_launch": fetch2 + write, "algorithmic_bytes_per_launch": 38 * W * H * B, "kernel_us_serialised": fe["dur_us"],
         "source": "committed PMC passes profiles/%s_pmc_fetch_write_size_config%d_background_prep_%d.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                   "runs of bench.py, tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note; counter collection serialises the kernels)" % (tag, cfg, bgp)}
+    # the background preparation's kernel: its own HBM bytes from the same passes, its instruction counts from a third one
+    fv = os.path.join(d, "pmc_valu_config%d_background_prep_%d.txt" % (cfg, bgp))
+    if bgp and os.path.exists(fv):
+        pf, pw, pv = kernel_value(f, "FETCH_SIZE", "bgprep"), kernel_value(f.replace("fetch", "write"), "WRITE_SIZE", "bgprep"), kernel_value(fv, "SQ_INSTS_VALU", "bgprep")
+        if pv:
+            tj["config%d_background_prep_%d" % (cfg, bgp)]["background_prep_kernel"] = {
+                "kernel": pv["kernel"], "valu_instructions_per_launch": pv["SQ_INSTS_VALU"], "salu_instructions_per_launch": pv.get("SQ_INSTS_SALU"),
+                "wave_cycles_per_launch": pv.get("SQ_WAVE_CYCLES"), "wave_cycles_waiting_per_launch": pv.get("SQ_WAIT_INST_ANY"),
+                "kernel_us_serialised": pv["dur_us"],
+                "hbm_bytes_per_launch": int(pf["FETCH_SIZE"] * 1024 * 2 + pw["WRITE_SIZE"] * 1024) if pf and pw else None,
+                "source": "profiles/%s_pmc_valu_config%d_background_prep_%d.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY over bench.py, "
+                          "tools/profile_round.sh; wave instructions summed over the launch's waves)" % (tag, cfg, bgp)}
+            with open(os.path.join(root, "profiles", "%s_pmc_valu_config%d_background_prep_%d.txt" % (tag, cfg, bgp)), "w") as o:
+                o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY over bench.py --config %d --background-prep %d --steps 60; per kernel: "
+                        "average per launch (kernels serialised by the collection)\n" % (cfg, bgp))
+                o.write(open(fv).read())
     with open(os.path.join(root, "profiles", "%s_pmc_fetch_write_size_config%d_background_prep_%d.txt" % (tag, cfg, bgp)), "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE (first block) and --pmc WRITE_SIZE (second block), separate passes over bench.py --config %d --background-prep %d "
                 "--steps 60; per kernel: average of the counter (KB) and of the duration (us; kernels serialised by the collection)\n" % (cfg, bgp))

@@ -1944,9 +1944,15 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // memory.  C and M never leave the CU, the per-column table entries are loaded once per tile instead of once per texel,
 // and the two launches (with the round trip of C through HBM between them) become one.  The tiles of all samples are
 // numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
-constexpr int kFuseW = 64, kFuseH = 32;
-constexpr int kFuseCW = 90, kFuseCH = 48;  // 64 * 4/3 + 2 columns (even: texel pairs), 32 * 4/3 + 2 rows, and a margin for the +2 of the crop size
-constexpr int kFuseWaves = 4, kFuseThreads = 64 * kFuseWaves;
+#ifndef OFDG_FUSE_H
+#define OFDG_FUSE_H 16     // (experiment builds override the geometry: profiles/r04_experiments_log.md section 14)
+#endif
+#ifndef OFDG_FUSE_WAVES
+#define OFDG_FUSE_WAVES 2
+#endif
+constexpr int kFuseW = 64, kFuseH = OFDG_FUSE_H;
+constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 6;  // 64 * 4/3 + 2 columns (even: texel pairs), 32 * 4/3 + 2 rows, and a margin for the +2 of the crop size
+constexpr int kFuseWaves = OFDG_FUSE_WAVES, kFuseThreads = 64 * kFuseWaves;
 constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
 constexpr int kFuseMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // What one tile costs is not its arithmetic but the small dependent loads around it - which sample holds tile t, that

@@ -1132,9 +1132,9 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
 #ifndef OFDG_FUSE_GRID
-#define OFDG_FUSE_GRID 1024
+#define OFDG_FUSE_GRID 2048
 #endif
-  constexpr int kBgPrepFusedBlocks = OFDG_FUSE_GRID;  // four workgroups per CU walk the batch's tiles (384: -3 %, 512 / 768: -2 %, profiles/r04_experiments_log.md)
+  constexpr int kBgPrepFusedBlocks = OFDG_FUSE_GRID;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
   if (staged) {
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;

@@ -7,7 +7,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ofdg = importlib.import_module("optical-flow-2d-data-generation_amd")
-names = ["top: records, this tile's piece of C, table requests", "rotation pass", "barrier", "X resize + barrier", "Y resize", "barrier", "-"]
+names = ["top: records, this tile's piece of C, table requests", "rotation pass", "barrier", "X resize + barrier", "Y resize", "barrier", "(of top: records + this tile's piece of C)"]
 outs = [ofdg.alloc_outputs(32, 384, 512) for _ in range(8)]
 for chains in (1, 4):
     g = ofdg.Generator(ofdg.default_params(width=512, height=384, mode=5, num_objects=16, batch_size=32, sampler=1, seed=20261003, background_prep=1, chains=chains))

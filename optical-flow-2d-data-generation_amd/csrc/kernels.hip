@@ -1951,7 +1951,7 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 #define OFDG_FUSE_WAVES 2
 #endif
 constexpr int kFuseW = 64, kFuseH = OFDG_FUSE_H;
-constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 6;  // 64 * 4/3 + 2 columns (even: texel pairs), 32 * 4/3 + 2 rows, and a margin for the +2 of the crop size
+constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 4;  // 64 * 4/3 + 2 columns (even: texel pairs) and a margin for the +2 of the crop size; kFuseH * 4/3 + 2 rows and the same margin (25 for 16 rows)
 constexpr int kFuseWaves = OFDG_FUSE_WAVES, kFuseThreads = 64 * kFuseWaves;
 constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
 constexpr int kFuseMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
@@ -2109,7 +2109,7 @@ __device__ unsigned long long g_fuse_stamps[8];
 __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
                                                            int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
   __shared__ uint32_t s_c[kFuseCH][kFuseCW];
-  __shared__ int s_first[kFuseMaxSamples + 1];  // tiles of the samples before sample i
+  extern __shared__ int s_first[];  // [n_samples + 1]: tiles of the samples before sample i (sized by the launch: LDS the other chains' raster and geom workgroups need is not held for batches that do not exist)
   const int TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef OFDG_FUSE_STAMPS

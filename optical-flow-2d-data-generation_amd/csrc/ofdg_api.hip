@@ -1146,7 +1146,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
   if (fusable && n <= kFuseMaxSamples) {
-    hipExtLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), 0, s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
+    hipExtLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), (size_t)(n + 1) * sizeof(int), s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }

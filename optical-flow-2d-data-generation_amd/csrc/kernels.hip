@@ -1944,15 +1944,9 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // memory.  C and M never leave the CU, the per-column table entries are loaded once per tile instead of once per texel,
 // and the two launches (with the round trip of C through HBM between them) become one.  The tiles of all samples are
 // numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
-#ifndef OFDG_FUSE_H
-#define OFDG_FUSE_H 16     // (experiment builds override the geometry: profiles/r04_experiments_log.md section 14)
-#endif
-#ifndef OFDG_FUSE_WAVES
-#define OFDG_FUSE_WAVES 2
-#endif
-constexpr int kFuseW = 64, kFuseH = OFDG_FUSE_H;
+constexpr int kFuseW = 64, kFuseH = 16;  // (other geometries measured: profiles/r04_experiments_log.md section 14)
 constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 4;  // 64 * 4/3 + 2 columns (even: texel pairs) and a margin for the +2 of the crop size; kFuseH * 4/3 + 2 rows and the same margin (25 for 16 rows)
-constexpr int kFuseWaves = OFDG_FUSE_WAVES, kFuseThreads = 64 * kFuseWaves;
+constexpr int kFuseWaves = 2, kFuseThreads = 64 * kFuseWaves;
 constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
 constexpr int kFuseMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // What one tile costs is not its arithmetic but the small dependent loads around it - which sample holds tile t, that
@@ -2096,15 +2090,6 @@ __device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k
   }
   return out;
 }
-#ifdef OFDG_FUSE_STAMPS
-// experiment builds: wall-clock ticks (10 ns) per pass, summed over the tiles of thread 0 of every workgroup; [7] = tiles
-__device__ unsigned long long g_fuse_stamps[8];
-// (summed in registers, flushed once when the workgroup is done: an atomic per stamp would sit in the same in-order memory
-//  counter as the loads the kernel waits for)
-#define FUSE_STAMP(i) do { const long long now_ = wall_clock64(); acc_[i] += (unsigned)(now_ - stamp_); stamp_ = now_; } while (0)
-#else
-#define FUSE_STAMP(i) do { } while (0)
-#endif
 // (six waves per SIMD: at most 80 VGPRs, so that its waves fit beside the compose kernel's)
 __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
                                                            int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
@@ -2112,10 +2097,6 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
   extern __shared__ int s_first[];  // [n_samples + 1]: tiles of the samples before sample i (sized by the launch: LDS the other chains' raster and geom workgroups need is not held for batches that do not exist)
   const int TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef OFDG_FUSE_STAMPS
-  long long stamp_ = wall_clock64();
-  unsigned acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   // ---- the tiles of all samples are numbered consecutively: prefix of their counts (wave 0, 64 samples at a time) ----
   if (wave == 0) {
     int running = 0;
@@ -2197,7 +2178,6 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       vx0 = T.at_x[tab_index(qn.cw, TW, nxt.bx0)]; vx1 = T.at_x[tab_index(qn.cw, TW, nxt.bx1)];
       vy0 = T.at_y[tab_index(qn.ch, TH, nxt.by0)]; vy1 = T.at_y[tab_index(qn.ch, TH, nxt.by1)];
     }
-    FUSE_STAMP(0);
     if (!cur.fits) {  // (a crop beyond 4/3 of the texture: the host launches the two-kernel form for such pools)
       if (tid == 0) atomicOr(err, kErrBgPrepCapacity);
     } else {
@@ -2205,9 +2185,6 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       const int pairs = (ncw + 1) / 2;
       const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48 (pairs <= 45; both factors below 2^24)
       if (cur.inside) {
-#ifdef OFDG_FUSE_UNROLL
-#pragma unroll OFDG_FUSE_UNROLL
-#endif
         for (int k = tid; k < pairs * nch; k += kFuseThreads) {
           const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
           const int pi = k - jj * pairs;
@@ -2228,9 +2205,7 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
         }
       }
     }
-    FUSE_STAMP(1);
     __syncthreads();
-    FUSE_STAMP(2);
     // (the entries requested in S2 have arrived behind the rotation pass's own loads; taken over into scalar registers here,
     //  before this tile's stores: vmcnt counts loads and stores in order, a later wait would also wait for the stores)
     ex0 = __builtin_amdgcn_readfirstlane(vx0); ex1 = __builtin_amdgcn_readfirstlane(vx1);
@@ -2250,7 +2225,6 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       }
     }
     __syncthreads();
-    FUSE_STAMP(3);
     if (cur.fits && x <= bx1) {
       // ---- Y pass: B(x, y) over M(x, .): wave w takes rows kFuseRows w .. of the tile ----
       uint32_t* Bs = B + (size_t)cur.s * TW * TH;
@@ -2269,15 +2243,8 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
         if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, yw, yw.exact, ys, cur.cy1, ydiv, ydiv24, [&](int j) { return s_c[j - cy0][lane]; });
       }
     }
-    FUSE_STAMP(4);
-#ifdef OFDG_FUSE_STAMPS
-    acc_[7] += 1;
-    if (!more && tid == 0)
-      for (int i = 0; i < 8; ++i) atomicAdd(&g_fuse_stamps[i], (unsigned long long)acc_[i]);
-#endif
     if (!more) break;
     __syncthreads();  // (the next tile overwrites the rows)
-    FUSE_STAMP(5);
     cur = nxt;
     t = tn;
   }

@@ -1131,10 +1131,7 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
   bgprep_caps(c, &cap_cw, &cap_ch, &fusable);
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
-#ifndef OFDG_FUSE_GRID
-#define OFDG_FUSE_GRID 2048
-#endif
-  constexpr int kBgPrepFusedBlocks = OFDG_FUSE_GRID;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
+  constexpr int kBgPrepFusedBlocks = 2048;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
   if (staged) {
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;
@@ -1932,17 +1929,6 @@ int ofdg_debug_tables(ofdg_ctx* c, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* 
   HIP_OK(c, hipFree(d));
   return OFDG_OK;
 }
-
-#ifdef OFDG_FUSE_STAMPS
-// experiment builds: read (and clear) the per-pass tick sums of bgprep_fused_kernel
-int ofdg_debug_fuse_stamps(unsigned long long* out8) {
-  if (hipDeviceSynchronize() != hipSuccess) return OFDG_EHIP;
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fuse_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return OFDG_EHIP;
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_stamps), z, sizeof(z)) != hipSuccess) return OFDG_EHIP;
-  return OFDG_OK;
-}
-#endif
 
 // include/ofdg_detmath.h on the device: n angles -> sin, cos; m floats -> expf (host arrays)
 int ofdg_debug_detmath(ofdg_ctx* c, const double* angles, int n, double* sin_out, double* cos_out, const float* x, int m, float* expf_out) {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer experiment: where a tile of bgprep_fused_kernel spends its time (a library built with -DOFDG_FUSE_STAMPS:
-tools/build_variant.sh stamps -DOFDG_FUSE_STAMPS ...; OFDG_LIB=.../libofdg_stamps.so).  Wall-clock ticks of wave 0 of every
+"""Developer experiment: where a tile of bgprep_fused_kernel spends its time (a library built from the tree with
+tools/patches/r04_bgprep_stamps_and_geometry_macros.patch applied and -DOFDG_FUSE_STAMPS: tools/build_variant.sh stamps -DOFDG_FUSE_STAMPS;
+OFDG_LIB=.../libofdg_stamps.so).  Wall-clock ticks of wave 0 of every
 workgroup per pass, alone (one chain) and in the pipeline (four chains)."""
 import ctypes as C, importlib, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

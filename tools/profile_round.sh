@@ -27,9 +27,9 @@ for arm in "2 1" "2 0" "3 1"; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c${cfg}_p$bgp -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $cfg --background-prep $bgp --no-cpu-baseline --no-secondary --steps 60 > /dev/null 2>&1
 done
 echo "[rocprofv3] pmc instruction counts, config 2 background_prep 1"
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_valu_c2_p1 -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config 2 --background-prep 1 --no-cpu-baseline --no-secondary --steps 60 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $out/pmcdir_valu_c2_p1 -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config 2 --background-prep 1 --no-cpu-baseline --no-secondary --steps 60 > /dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"
-python3 tools/pmcstats.py $out/pmc_valu_c2_p1 > $out/pmc_valu_config2_background_prep_1.txt
+python3 tools/pmcstats.py $out/pmcdir_valu_c2_p1 > $out/pmc_valu_config2_background_prep_1.txt
 python3 tools/kstats.py $out/trace > $out/kernel_stats.txt
 cp $(ls $out/trace/*kernel_stats.csv $out/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats.csv 2>/dev/null
 for arm in "2 1" "2 0" "3 1"; do
@@ -37,7 +37,7 @@ for arm in "2 1" "2 0" "3 1"; do
   python3 tools/pmcstats.py $out/pmc_fetch_c${cfg}_p$bgp > $out/pmc_fetch_size_config${cfg}_background_prep_$bgp.txt
   python3 tools/pmcstats.py $out/pmc_write_c${cfg}_p$bgp > $out/pmc_write_size_config${cfg}_background_prep_$bgp.txt
 done
-rm -rf $out/trace $out/pmc_fetch_c* $out/pmc_write_c* $out/pmc_valu_c*
+rm -rf $out/trace $out/pmc_fetch_c* $out/pmc_write_c* $out/pmcdir_valu_c*
 tail -n 12 $out/kernel_stats.txt; grep -A3 compose $out/pmc_fetch_size_config2_background_prep_1.txt $out/pmc_write_size_config2_background_prep_1.txt; python3 -c "
 import json,glob
 for f in sorted(glob.glob('$out/bench_line*.json')):

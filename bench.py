@@ -412,8 +412,8 @@ def main():
 
     compose_ms = gen.kernel_ms("compose")
     parts = alone = cpu_base = None
-    # the background preparation's launch is timed where it runs behind raster (every mode but 9; device-sampled batches)
-    names = ("geom", "raster", "compose") + (("background_prep",) if bgp and counter and cfg["mode"] != 9 else ())
+    # the background preparation's launch is timed where it runs behind raster (batches the library prepares itself)
+    names = ("geom", "raster", "compose") + (("background_prep",) if bgp and counter else ())
     prep_ms = gen.kernel_ms("background_prep") if "background_prep" in names else None
     if rank == 0:
         # second short pass with all three kernels timed (not part of `value`)

@@ -325,7 +325,7 @@ int ofdg_debug_detmath(ofdg_ctx* ctx, const double* angles, int n, double* sin_o
 /* Per-kernel device time (ms), averaged over the launches recorded since ofdg_set_profiling (mode 1: the compose launch
  * and the background preparation of every 4th batch, completion signals on the kernels' own packets, nothing added to the
  * streams; mode 2: every kernel of every batch, with start markers; 0: off).  Names: "geom", "raster" (mode 2), "compose",
- * "background_prep" (where the preparation runs behind raster: every mode but 9, batches the library prepares itself). */
+ * "background_prep" (where the preparation runs behind raster: batches the library prepares itself). */
 int ofdg_set_profiling(ofdg_ctx* ctx, int mode);
 int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
 

@@ -958,13 +958,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
     int rc = launch_counter_sampler(c, sl, cs_first_index, S, err);
     if (rc != OFDG_OK) return rc;
   }
-  // The background preparation of the batch: LAST, right in front of compose (below) - except in mode 9, whose compose kernel
-  // is ALU-heavy itself (there the preparation goes first: 243 k against 235 k samples/s; profiles/r04_experiments_log.md section 11)
-  if (sl.bgprep_pending && c->prm.mode == 9) {
-    int rcb = prepare_backgrounds(c, sl, sl.res_samples, /*records_resident=*/true, S, err);
-    if (rcb != OFDG_OK) return rcb;
-    sl.bgprep_pending = false;
-  }
+  // (the background preparation of the batch goes LAST, right in front of compose: below)
   // geom: outlines, bounding boxes, per-object boxes (parity `bp`), raster work list
   const int bp = sl.box_parity;
   sl.box_parity ^= 1;
@@ -1884,7 +1878,7 @@ int ofdg_kernel_ms(ofdg_ctx* c, const char* kernel, float* ms) {
   if (!std::strcmp(kernel, "geom")) i = 0;
   else if (!std::strcmp(kernel, "raster")) i = 1;
   else if (!std::strcmp(kernel, "compose")) i = 2;
-  else if (!std::strcmp(kernel, "background_prep")) i = 3;  // (timed where it runs behind raster: not in mode 9, not for a caller's slot prepared at its upload)
+  else if (!std::strcmp(kernel, "background_prep")) i = 3;  // (timed where it runs behind raster: not for a caller's slot prepared at its upload)
   if (i < 0) { c->err = "unknown kernel name"; return OFDG_EINVAL; }
   if (!c->profiling || c->ev_count == 0 || (i < 2 && c->profiling != 2)) {
     c->err = "no profiled launch of that kernel yet (ofdg_set_profiling)";

@@ -562,9 +562,10 @@ struct RasterWs {
 // One item = one outline x one band of kBandRows scanlines x the padded column range [X0, X1], by ONE wave (no
 // workgroup barriers): clear its cells, accumulate every (edge, scanline) pair of the outline that can reach the
 // chunk, sweep, store the coverage bytes, mark the block masks.  v: the outline's nv vertices; F*: its pixel box.
+// pa, pb: v[lane] and v[lane + 1], requested by the caller while the previous item was being rasterised.
 __device__ __forceinline__ void raster_item(RasterWs& ws, const int2* __restrict__ v, int nv, int Fx0, int Fy0, int Fx1, int Fy1, int sf,
                                             int band, int X0, int X1, int W, int H, uint8_t* __restrict__ cov,
-                                            unsigned long long* __restrict__ blockmask, int sample, int obj_local, int lane) {
+                                            unsigned long long* __restrict__ blockmask, int sample, int obj_local, int lane, int2 pa, int2 pb) {
   ChunkCells& tc = ws.cells;
   const int by0 = band * kBandRows;
   const int rows = min(kBandRows, H - by0);
@@ -594,9 +595,14 @@ __device__ __forceinline__ void raster_item(RasterWs& ws, const int2* __restrict
   for (int e0 = 0; e0 < nv; e0 += 64) {
     const int e = e0 + lane;
     int n_rows = 0, rlo = 0;
+    // this lane's edge (a -> b); the first 64 edges' vertices are in hand already
+    int2 a = pa, b = pb;
+    if (e0 > 0 && e < nv) { a = v[e]; b = v[e + 1]; }        // (v[nv] is inside the outline's slot: read, then replaced below)
+    {
+      const int v0x = __shfl(pa.x, 0, 64), v0y = __shfl(pa.y, 0, 64);  // the closing edge ends at vertex 0
+      if (e + 1 == nv) b = make_int2(v0x, v0y);
+    }
     if (e < nv) {
-      const int2 a = v[e];
-      const int2 b = v[(e + 1 == nv) ? 0 : e + 1];
       const int eya = a.y >> 8, eyb = b.y >> 8;
       rlo = max(min(eya, eyb), by0);
       const int rhi = min(max(eya, eyb), by0 + rows - 1);
@@ -609,13 +615,10 @@ __device__ __forceinline__ void raster_item(RasterWs& ws, const int2* __restrict
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
-      if (q < total) {
-        const int code = queue[q];
-        const int ee = code >> 4, r = code & 15;
-        const int2 a = v[ee];
-        const int2 b = v[(ee + 1 == nv) ? 0 : ee + 1];
-        edge_scanline(acc, r, by0 + r, a.x, a.y, b.x, b.y);
-      }
+      const int code = (q < total) ? queue[q] : (e0 << 4);
+      const int src = (code >> 4) - e0, r = code & 15;   // the pair's edge sits in lane `src` of this block: no second trip to memory
+      const int ax = __shfl(a.x, src, 64), ay = __shfl(a.y, src, 64), bx = __shfl(b.x, src, 64), by = __shfl(b.y, src, 64);
+      if (q < total) edge_scanline(acc, r, by0 + r, ax, ay, bx, by);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
@@ -661,13 +664,43 @@ __global__ __launch_bounds__(64 * kRasterWaves) void raster_kernel(const DevShap
   for (int gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_mask_words; gid += gridDim.x * blockDim.x) blockmask_next[gid] = 0ull;
   const int n_items = *item_count;
   const int n_waves = gridDim.x * kRasterWaves;
-  for (int it = blockIdx.x * kRasterWaves + wave; it < n_items; it += n_waves) {
-    const int4 item = items[it];
-    const int sf = __builtin_amdgcn_readfirstlane(item.x), band = __builtin_amdgcn_readfirstlane(item.y);
-    const int X0 = __builtin_amdgcn_readfirstlane(item.z), X1 = __builtin_amdgcn_readfirstlane(item.w);
-    const DevShapeFrame F = frames[sf];
-    raster_item(s_ws[wave], verts + (size_t)sf * kMaxVerts, F.n_verts, F.x0, F.y0, F.x1, F.y1, sf, band, X0, X1, W, H, cov, blockmask,
-                F.pad[0], F.pad[1], lane);
+  // An item is three dependent trips to memory before its first instruction of work (the item, its outline's record, the
+  // vertices): the loop is a software pipeline - item k + 2, the record of item k + 1 and its first 64 vertices are requested
+  // before item k is rasterised.  The work list and the records are constant while this kernel runs (scalar loads).
+  typedef OFDG_CONSTANT const int4 ConstItem;
+  typedef OFDG_CONSTANT const DevShapeFrame ConstFrame;
+  int it = __builtin_amdgcn_readfirstlane(blockIdx.x * kRasterWaves + wave);
+  if (it >= n_items) return;
+  // (what is carried around the loop is a per-lane value to the compiler: readfirstlane says "uniform" again)
+  struct Item { int sf, band, X0, X1; };
+  struct Frame { int nv, x0, y0, x1, y1, sample, obj_local; };
+  auto item_at = [&](int i) {
+    const int4 q = ((ConstItem*)items)[i];
+    return Item{q.x, q.y, q.z, q.w};
+  };
+  auto frame_of = [&](int sf) {
+    const ConstFrame& f = ((ConstFrame*)frames)[sf];
+    return Frame{f.n_verts, f.x0, f.y0, f.x1, f.y1, f.pad[0], f.pad[1]};
+  };
+  auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  int it1 = it + n_waves;
+  Item I0 = item_at(it), I1 = item_at(it1 < n_items ? it1 : it);
+  Frame F0 = frame_of(I0.sf);
+  int2 pa = verts[(size_t)I0.sf * kMaxVerts + lane], pb = verts[(size_t)I0.sf * kMaxVerts + lane + 1];
+  for (;;) {
+    I0 = Item{uni(I0.sf), uni(I0.band), uni(I0.X0), uni(I0.X1)};
+    I1 = Item{uni(I1.sf), uni(I1.band), uni(I1.X0), uni(I1.X1)};
+    F0 = Frame{uni(F0.nv), uni(F0.x0), uni(F0.y0), uni(F0.x1), uni(F0.y1), uni(F0.sample), uni(F0.obj_local)};
+    it1 = uni(it1);
+    const int it2 = it1 + n_waves;
+    const Item I2 = item_at(it2 < n_items ? it2 : it1 < n_items ? it1 : it);
+    const Frame F1 = frame_of(I1.sf);
+    const int2 na = verts[(size_t)I1.sf * kMaxVerts + lane], nb = verts[(size_t)I1.sf * kMaxVerts + lane + 1];
+    raster_item(s_ws[wave], verts + (size_t)I0.sf * kMaxVerts, F0.nv, F0.x0, F0.y0, F0.x1, F0.y1, I0.sf, I0.band, I0.X0, I0.X1, W, H, cov, blockmask,
+                F0.sample, F0.obj_local, lane, pa, pb);
+    if (it1 >= n_items) break;
+    I0 = I1; F0 = F1; I1 = I2; pa = na; pb = nb;
+    it = it1; it1 = it2;
   }
 }
 

@@ -352,6 +352,11 @@ int ofdg_host_realize(const ofdg_params* prm, int pool_n, int pool_w, int pool_h
 int ofdg_host_bg_prep(int pool_w, int pool_h, int width, int height, float angle, float zoom,
                       int shift_x, int shift_y, float* f, int* i);
 
+/* One image file of a texture list as the layer's loader decodes it (TextureCollection, DG:117-149: CImg::load, then
+ * R <-> B): binary PPM natively, PNG through the system's libpng 1.6 (bound at run time).  planar_bgr: 3 planes of
+ * width x height bytes (B, G, R), or NULL to ask for the size only. */
+int ofdg_host_decode_image(const char* path, uint8_t* planar_bgr, size_t capacity, int* width, int* height);
+
 /* Parse a `layer { ... }` prototxt block (example-prototxt/train.prototxt). */
 int ofdg_parse_prototxt(const char* text, ofdg_params* out, char* texture_dbases,
                         int texture_dbases_cap, int* n_top);

@@ -94,7 +94,7 @@ EXPORTS = [
     "ofdg_set_profiling", "ofdg_kernel_ms", "ofdg_debug_graph_capture", "ofdg_debug_graph_launch", "ofdg_debug_graph_destroy",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
-    "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
+    "ofdg_parse_prototxt", "ofdg_host_last_error", "ofdg_host_decode_image", "ofdg_layer_create", "ofdg_layer_forward", "ofdg_layer_destroy",
     "ofdg_layer_in_flight", "ofdg_poll_errors", "ofdg_poll_errors_of", "ofdg_last_ticket", "ofdg_num_chains",
     "ofdg_comm_unique_id", "ofdg_comm_init", "ofdg_comm_adopt", "ofdg_comm_destroy", "ofdg_comm_rank", "ofdg_comm_world_size",
     "ofdg_comm_last_error", "ofdg_comm_bcast_setup", "ofdg_comm_bcast_abort", "ofdg_comm_nccl_count", "ofdg_comm_bcast_pool", "ofdg_comm_agree", "ofdg_setup_of", "ofdg_setup_params",
@@ -510,6 +510,24 @@ class Generator:
         ms = C.c_float()
         self._check(lib().ofdg_kernel_ms(self.h, name.encode(), C.byref(ms)))
         return ms.value
+
+
+def decode_image(path):
+    """One image file as the layer's native loader decodes it (binary PPM, or PNG through the system's libpng):
+    uint8 array [3, h, w] in B, G, R order.  No GPU needed."""
+    import numpy as np
+    w, h = C.c_int(), C.c_int()
+    L = lib()
+    L.ofdg_host_decode_image.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ofdg_host_last_error.restype = C.c_char_p
+    rc = L.ofdg_host_decode_image(str(path).encode(), None, 0, C.byref(w), C.byref(h))
+    if rc != OK:
+        raise OfdgError(rc, L.ofdg_host_last_error().decode())
+    out = np.empty((3, h.value, w.value), dtype=np.uint8)
+    rc = L.ofdg_host_decode_image(str(path).encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(w), C.byref(h))
+    if rc != OK:
+        raise OfdgError(rc, L.ofdg_host_last_error().decode())
+    return out
 
 
 class Comm:

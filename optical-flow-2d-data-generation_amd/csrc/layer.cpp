@@ -2,6 +2,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -205,6 +207,72 @@ bool read_ppm(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w,
   }
   return true;
 }
+
+// PNG through the system's libpng 1.6, bound at run time (dlopen: the library is part of the image, a build dependency on
+// it is not wanted).  Its "simplified API" (png.h 1.6: png_image_begin_read_from_file / png_image_finish_read /
+// png_image_free over a caller-owned png_image) is a stable C ABI; the struct below restates png_image field by field.
+// 8-bit R, G, B, A come back as stored (alpha is read and dropped: CImg's load keeps it as a fourth channel the
+// reference never looks at, DataGenerator.cpp:128-131); palette, grey and 16-bit files are expanded by libpng.
+struct PngImage {
+  void* opaque;
+  uint32_t version, width, height, format, flags, colormap_entries, warning_or_error;
+  char message[64];
+};
+struct PngApi {
+  int (*begin_read_from_file)(PngImage*, const char*) = nullptr;
+  int (*finish_read)(PngImage*, const void* background, void* buffer, int32_t row_stride, void* colormap) = nullptr;
+  void (*image_free)(PngImage*) = nullptr;
+  bool ok = false;
+  PngApi() {
+    void* h = nullptr;
+    for (const char* name : {"libpng16.so.16", "libpng16.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return;
+    begin_read_from_file = (decltype(begin_read_from_file))dlsym(h, "png_image_begin_read_from_file");
+    finish_read = (decltype(finish_read))dlsym(h, "png_image_finish_read");
+    image_free = (decltype(image_free))dlsym(h, "png_image_free");
+    ok = begin_read_from_file && finish_read && image_free;
+  }
+};
+const PngApi& png_api() { static const PngApi api; return api; }
+constexpr uint32_t kPngImageVersion = 1, kPngFormatRgba = 0x03;  // PNG_IMAGE_VERSION; PNG_FORMAT_FLAG_ALPHA | PNG_FORMAT_FLAG_COLOR
+
+bool is_png(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  unsigned char sig[8] = {0};
+  f.read((char*)sig, 8);
+  static const unsigned char want[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  return f.gcount() == 8 && std::memcmp(sig, want, 8) == 0;
+}
+// planar_bgr == nullptr: the size only
+bool read_png(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w, int* h, std::string* why) {
+  const PngApi& api = png_api();
+  if (!api.ok) { *why = "libpng16 is not available on this system"; return false; }
+  PngImage img;
+  std::memset(&img, 0, sizeof(img));
+  img.version = kPngImageVersion;
+  if (!api.begin_read_from_file(&img, path.c_str())) { *why = img.message; return false; }
+  *w = (int)img.width; *h = (int)img.height;
+  if (!planar_bgr) { api.image_free(&img); return true; }
+  img.format = kPngFormatRgba;
+  const size_t n = (size_t)img.width * img.height;
+  std::vector<uint8_t> rgba(n * 4);
+  if (!api.finish_read(&img, nullptr, rgba.data(), 0, nullptr)) { *why = img.message; api.image_free(&img); return false; }
+  planar_bgr->resize(3 * n);
+  for (size_t i = 0; i < n; ++i) {  // planar, R <-> B swapped like the PPM path (DataGenerator.cpp:129-131)
+    (*planar_bgr)[i] = rgba[4 * i + 2];
+    (*planar_bgr)[n + i] = rgba[4 * i + 1];
+    (*planar_bgr)[2 * n + i] = rgba[4 * i + 0];
+  }
+  return true;
+}
+// An image file of a texture list: binary PPM or PNG, by its first bytes.  planar_bgr == nullptr: the size only.
+bool read_image(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w, int* h, std::string* why) {
+  if (is_png(path)) return read_png(path, planar_bgr, w, h, why);
+  std::vector<uint8_t> scratch;
+  if (read_ppm(path, planar_bgr ? planar_bgr : &scratch, w, h)) return true;
+  *why = "neither a binary PPM (P6, maxval 255) nor a PNG";
+  return false;
+}
 }  // namespace
 
 void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
@@ -232,14 +300,19 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
   std::vector<std::vector<uint8_t>> first(1);
   int pw = 0, ph = 0;
   bool mixed = false;
-  for (size_t i = 0; i < paths.size() && !mixed; ++i) {  // headers decide (cheap: the pixel data of the first image only)
-    std::ifstream f(paths[i], std::ios::binary);
-    std::string magic;
+  for (size_t i = 0; i < paths.size() && !mixed; ++i) {  // headers decide
     int w = 0, h = 0;
-    if (!f.is_open() || !(f >> magic) || magic != "P6") throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + " as binary PPM)");
-    for (int k = 0; k < 2; ++k) {
-      for (;;) { const int ch = f.peek(); if (ch == '#') { std::string line; std::getline(f, line); } else if (std::isspace(ch)) f.get(); else break; }
-      f >> (k == 0 ? w : h);
+    std::string why;
+    if (is_png(paths[i])) {
+      if (!read_png(paths[i], nullptr, &w, &h, &why)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + ": " + why + ")");
+    } else {
+      std::ifstream f(paths[i], std::ios::binary);
+      std::string magic;
+      if (!f.is_open() || !(f >> magic) || magic != "P6") throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + ": neither a binary PPM nor a PNG)");
+      for (int k = 0; k < 2; ++k) {
+        for (;;) { const int ch = f.peek(); if (ch == '#') { std::string line; std::getline(f, line); } else if (std::isspace(ch)) f.get(); else break; }
+        f >> (k == 0 ? w : h);
+      }
     }
     if (i == 0) { pw = w; ph = h; } else if (w != pw || h != ph) mixed = true;
   }
@@ -248,7 +321,8 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
   for (size_t i = 0; i < paths.size(); ++i) {
     std::vector<uint8_t> img;
     int w = 0, h = 0;
-    if (!read_ppm(paths[i], &img, &w, &h)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + " as binary PPM)");
+    std::string why;
+    if (!read_image(paths[i], &img, &w, &h, &why)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + ": " + why + ")");
     const int rc = mixed ? ofdg_pool_upload_mixed(ctx, (int)i, img.data(), w, h) : ofdg_pool_upload(ctx, (int)i, img.data(), w, h);
     if (rc != OFDG_OK) throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
   }
@@ -433,6 +507,18 @@ static thread_local std::string g_host_error;
 extern "C" {
 
 const char* ofdg_host_last_error(void) { return g_host_error.c_str(); }
+
+int ofdg_host_decode_image(const char* path, uint8_t* planar_bgr, size_t capacity, int* width, int* height) {
+  if (!path || !width || !height) return OFDG_EINVAL;
+  std::vector<uint8_t> img;
+  std::string why;
+  if (!read_image(path, planar_bgr ? &img : nullptr, width, height, &why)) { g_host_error = std::string("cannot read ") + path + ": " + why; return OFDG_ETEXTURES; }
+  if (planar_bgr) {
+    if (img.size() > capacity) { g_host_error = "image buffer too small"; return OFDG_ECAPACITY; }
+    std::memcpy(planar_bgr, img.data(), img.size());
+  }
+  return OFDG_OK;
+}
 
 int ofdg_host_sampler_create(int mode, int width, int height, int num_objects, ofdg_host_sampler** out) {
   if (!out) return OFDG_EINVAL;

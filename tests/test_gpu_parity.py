@@ -863,17 +863,22 @@ def test_mixed_size_pool_equals_uniform_pools_image_by_image(ofdg, oracle, prep)
 
 
 def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_path):
-    """The layer's TextureCollection loader (DG:117-149) with PPMs of three different sizes: the pool becomes a
+    """The layer's TextureCollection loader (DG:117-149) with images (PPM and PNG) of three different sizes: the pool becomes a
     mixed one; Forward() equals a Generator fed with the same images through ofdg_pool_upload_mixed."""
     import torch
     rng = np.random.RandomState(9)
     paths, planar = [], []
+    from PIL import Image
     for i, (ww, hh) in enumerate(((300, 220), (256, 192), (100, 64))):
         rgb = rng.randint(0, 256, (hh, ww, 3)).astype(np.uint8)
-        p = tmp_path / ("tex%d.ppm" % i)
-        with open(p, "wb") as f:
-            f.write(b"P6\n%d %d\n255\n" % (ww, hh))
-            f.write(rgb.tobytes())
+        if i == 1:   # (a PNG among the PPMs: decoded natively through the system's libpng)
+            p = tmp_path / ("tex%d.png" % i)
+            Image.fromarray(rgb).save(p)
+        else:
+            p = tmp_path / ("tex%d.ppm" % i)
+            with open(p, "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (ww, hh))
+                f.write(rgb.tobytes())
         paths.append(str(p))
         planar.append(np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))
     lst = tmp_path / "database.txt"

@@ -427,3 +427,43 @@ def test_tile_index_division_by_reciprocal_is_exact():
             assert k * inv < (1 << 32)
             assert (k * inv) >> 20 == k // pairs
 
+
+
+def test_native_image_decode_png_and_ppm(ofdg, tmp_path):
+    """The layer's texture loader decodes binary PPM itself and PNG through the system's libpng (bound at run time): same
+    texels as Pillow's decode, as planes in B, G, R order (TextureCollection swaps R and B, DataGenerator.cpp:129-131);
+    RGB, RGBA (alpha dropped), palette and grey PNGs; anything else is refused with the loader's message."""
+    from PIL import Image
+    rng = np.random.RandomState(4)
+    rgb = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    want = np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]])
+    p = tmp_path / "a.png"
+    Image.fromarray(rgb).save(p)
+    assert np.array_equal(ofdg.decode_image(p), want)
+    rgba = np.dstack([rgb, rng.randint(0, 256, (37, 53)).astype(np.uint8)])
+    p = tmp_path / "b.png"
+    Image.fromarray(rgba, "RGBA").save(p)
+    assert np.array_equal(ofdg.decode_image(p), want)                      # the stored colours, whatever the alpha
+    grey = rng.randint(0, 256, (20, 31)).astype(np.uint8)
+    p = tmp_path / "c.png"
+    Image.fromarray(grey, "L").save(p)
+    assert np.array_equal(ofdg.decode_image(p), np.stack([grey, grey, grey]))
+    pal = Image.fromarray(rgb).quantize(16)
+    p = tmp_path / "d.png"
+    pal.save(p)
+    q = np.asarray(pal.convert("RGB"))
+    assert np.array_equal(ofdg.decode_image(p), np.stack([q[:, :, 2], q[:, :, 1], q[:, :, 0]]))
+    p = tmp_path / "e.ppm"
+    with open(p, "wb") as f:
+        f.write(b"P6\n# a comment\n53 37\n255\n" + rgb.tobytes())
+    assert np.array_equal(ofdg.decode_image(p), want)
+    p = tmp_path / "f.bmp"
+    Image.fromarray(rgb).save(p)
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.decode_image(p)
+    assert e.value.code == ofdg.ETEXTURES and "neither a binary PPM" in str(e.value)
+    p = tmp_path / "g.png"
+    p.write_bytes(b"\x89PNG\r\n\x1a\n" + b"garbage" * 8)                     # a PNG signature and nothing behind it
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.decode_image(p)
+    assert e.value.code == ofdg.ETEXTURES

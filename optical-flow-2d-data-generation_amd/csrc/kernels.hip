@@ -1977,7 +1977,10 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // memory.  C and M never leave the CU, the per-column table entries are loaded once per tile instead of once per texel,
 // and the two launches (with the round trip of C through HBM between them) become one.  The tiles of all samples are
 // numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
-constexpr int kFuseW = 64, kFuseH = 16;  // (other geometries measured: profiles/r04_experiments_log.md section 14)
+// Two waves on 64 x 16 tiles and 9 KB of LDS: in the step's pipeline a workgroup costs the time it holds its LDS (the raster, geom
+// and sampler waves of the other chains wait for it), not what it executes - every KB ~ 1 % of the step, and forms of this kernel
+// that stage more (source windows in LDS, prefetches) are faster alone and slower in the step (profiles/r04_experiments_log.md sections 14, 15).
+constexpr int kFuseW = 64, kFuseH = 16;
 constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 4;  // 64 * 4/3 + 2 columns (even: texel pairs) and a margin for the +2 of the crop size; kFuseH * 4/3 + 2 rows and the same margin (25 for 16 rows)
 constexpr int kFuseWaves = 2, kFuseThreads = 64 * kFuseWaves;
 constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
@@ -2244,7 +2247,7 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
     ex0 = __builtin_amdgcn_readfirstlane(vx0); ex1 = __builtin_amdgcn_readfirstlane(vx1);
     ey0 = __builtin_amdgcn_readfirstlane(vy0); ey1 = __builtin_amdgcn_readfirstlane(vy1);
     if (cur.fits) {
-      // ---- X pass: M(x, j) over C(., j), in place: wave w takes rows w, w + 4, ...; lane = column of the tile ----
+      // ---- X pass: M(x, j) over C(., j), in place: wave w takes rows w, w + kFuseWaves, ...; lane = column of the tile ----
       const FixWeight xw = fix_weight(xal);
       const bool xfast = __ballot(x <= bx1 && !xw.exact) == 0ull;  // (the wave's columns all have exact weights: uniform)
       const uint32_t xdiv = 0xFFFFFFFFu / (uint32_t)p.cw + 1u;

@@ -597,7 +597,7 @@ __device__ __forceinline__ void raster_item(RasterWs& ws, const int2* __restrict
     int n_rows = 0, rlo = 0;
     // this lane's edge (a -> b); the first 64 edges' vertices are in hand already
     int2 a = pa, b = pb;
-    if (e0 > 0 && e < nv) { a = v[e]; b = v[e + 1]; }        // (v[nv] is inside the outline's slot: read, then replaced below)
+    if (e0 > 0 && e < nv) { a = v[e]; b = v[(e + 1 == nv) ? 0 : e + 1]; }  // (never past the outline's slot: nv may be kMaxVerts)
     {
       const int v0x = __shfl(pa.x, 0, 64), v0y = __shfl(pa.y, 0, 64);  // the closing edge ends at vertex 0
       if (e + 1 == nv) b = make_int2(v0x, v0y);

@@ -160,6 +160,23 @@ def test_rasteriser_offscreen_and_clipped(ofdg, oracle):
         assert np.array_equal(cov, exp), "case %d: %d px differ" % (i, (cov != exp).sum())
 
 
+def test_rasteriser_outlines_of_many_vertices(ofdg, oracle):
+    """Outlines whose edges fill several 64-edge blocks of a raster item - up to the full 1024 vertices of an outline's
+    slot (the last edge's end point is vertex 0, never the word behind the slot) - and blocks in which most edges miss the
+    item's band: the device rasteriser against the oracle's, bit for bit."""
+    W, H = 256, 192
+    g = make_gen(ofdg, W, H, 5)
+    rng = np.random.RandomState(11)
+    for n in (65, 128, 129, 500, 1023, 1024):
+        phi = (np.arange(n) + rng.uniform(-0.3, 0.3, n)) * 2 * np.pi / n
+        r = 70 + 20 * np.sin(7 * phi) + rng.uniform(-2, 2, n)       # a wobbly star: edges go up and down all around
+        xy = np.stack([128 + 1.4 * r * np.cos(phi), 96 + r * np.sin(phi)], 1)
+        cov = g.debug_rasterize(xy)
+        exp = oracle.rasterize(xy, W, H)
+        assert np.array_equal(cov, exp), "%d vertices: %d px differ" % (n, (cov != exp).sum())
+    g.synchronize()
+
+
 def test_rasteriser_long_edges_take_the_wide_arithmetic(ofdg, oracle):
     """Edges spanning 8 192 .. 16 383 px leave the 32-bit fast path of the closed-form cell stepping (64-bit / fp64
     quotients, csrc/kernels.hip edge_scanline / hline slow halves); AGG itself walks them incrementally in int32

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer experiment: when the workgroups of bgprep_fused_kernel start and how long they run, alone (one chain) and in the
+pipeline (four chains).  Needs a library built with tools/patches/r04_bgprep_workgroup_times.patch applied."""
 import ctypes as C, importlib, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -70,6 +70,7 @@ CONFIGS = {
 POOL_SEED = 2024
 NSLOT = 12
 SEED = 20261003
+EXIT_PORT_TAKEN = 98                    # a rank's exit code: the rendezvous port was taken between the launcher's probe and rank 0's bind
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # G wave64 vector instructions/s: 256 CUs x 4 SIMD16 at 2.4 GHz, 4 cycles per wave64 instruction
 
@@ -159,42 +160,55 @@ def launch(args, argv):
     import signal
     import socket
     import subprocess
+    import threading
     n = args.gpus
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
     child_argv = [a for a in argv if a != "--launcher"]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OFDG_BENCH_LAUNCHED="1")
-        env.setdefault("GLOO_SOCKET_IFNAME", "lo")       # the timing barrier runs over gloo on the loopback interface
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 or args.launch_only else subprocess.DEVNULL, text=True))
-    rc = 0
-    alive = set(range(n))
-    deadline = None
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                sys.stderr.write("bench.py launcher: rank %d exited with %d; stopping the other ranks\n" % (r, code))
-                deadline = time.time() + 20.0  # (they normally fail by themselves: the start-up is decided collectively)
-        if rc != 0 and alive and time.time() > deadline:
-            for r in alive:
-                procs[r].send_signal(signal.SIGTERM)  # exactly the PIDs started above
-            time.sleep(2.0)
-            for r in alive:
-                if procs[r].poll() is None:
-                    procs[r].kill()
-            deadline = time.time() + 60.0
-        time.sleep(0.02)
-    outs = [p.stdout.read() if p.stdout else "" for p in procs]
+    for attempt in range(3):
+        # The rendezvous port: bound and released here, bound again by rank 0's store.  Somebody else can take it in
+        # between; rank 0 then exits with EXIT_PORT_TAKEN and the whole start is repeated on another port.
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        procs, outs, readers = [], [[] for _ in range(n)], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OFDG_BENCH_LAUNCHED="1", OFDG_BENCH_ATTEMPT=str(attempt))
+            env.setdefault("GLOO_SOCKET_IFNAME", "lo")       # the timing barrier runs over gloo on the loopback interface
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 or args.launch_only else subprocess.DEVNULL, text=True))
+            if procs[r].stdout:  # drained while the child runs: a rank that prints more than a pipe holds must not block on it
+                t = threading.Thread(target=lambda f=procs[r].stdout, o=outs[r]: o.append(f.read()), daemon=True)
+                t.start()
+                readers.append(t)
+        rc = 0
+        alive = set(range(n))
+        deadline = None
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py launcher: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                    deadline = time.time() + 20.0  # (they normally fail by themselves: the start-up is decided collectively)
+            if rc != 0 and alive and time.time() > deadline:
+                for r in alive:
+                    procs[r].send_signal(signal.SIGTERM)  # exactly the PIDs started above
+                time.sleep(2.0)
+                for r in alive:
+                    if procs[r].poll() is None:
+                        procs[r].kill()
+                deadline = time.time() + 60.0
+            time.sleep(0.02)
+        for t in readers:
+            t.join()
+        if rc != EXIT_PORT_TAKEN:
+            break
+        sys.stderr.write("bench.py launcher: port %d was taken before rank 0 could bind it; starting again on another one\n" % port)
+    outs = ["".join(o) for o in outs]
     if args.launch_only:
         ranks = []
         for o in outs:
@@ -218,7 +232,12 @@ class Plumbing:
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group()  # default backends: gloo for CPU tensors, nccl (RCCL) for device tensors, the latter made on first use
+            try:
+                dist.init_process_group()  # default backends: gloo for CPU tensors, nccl (RCCL) for device tensors, the latter made on first use
+            except Exception as e:  # noqa: BLE001
+                if "OFDG_BENCH_LAUNCHED" in os.environ and any(k in str(e).lower() for k in ("address already in use", "eaddrinuse")):
+                    raise SystemExit(EXIT_PORT_TAKEN)  # (bench.py's own launcher picks another port and starts again)
+                raise
             self.dist = dist
             self.device = "cpu"
             try:
@@ -370,6 +389,9 @@ def main():
     if args.launch_only and launched:
         if os.environ.get("OFDG_BENCH_TEST_FAIL_RANK") == os.environ["RANK"]:  # (the launcher's test: a rank that dies)
             return 5
+        if os.environ.get("OFDG_BENCH_TEST_PORT_TAKEN") and os.environ["RANK"] == "0" and os.environ.get("OFDG_BENCH_ATTEMPT") == "0":
+            return EXIT_PORT_TAKEN  # (the launcher's test: rank 0 could not bind the rendezvous port at the first attempt)
+        sys.stdout.write("#" * int(os.environ.get("OFDG_BENCH_TEST_PAD", "0")) + "\n")  # (the launcher's test: more output than a pipe holds)
         print(json.dumps({k.lower(): (int(os.environ[k]) if os.environ[k].isdigit() else os.environ[k])
                           for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
         return 0

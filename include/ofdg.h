@@ -266,7 +266,11 @@ int ofdg_poll_errors(ofdg_ctx* ctx);
  * (OFDG_ECAPACITY, the message names the batch) - what a prefetch ring calls when it hands over a batch whose own completion
  * event it has waited for (prefetch_full_.pop, LAY:269), so that an error of batch k is reported at batch k's Forward, not
  * at an older batch's, and batches k - 1 and k + 1 stay valid.  (The reference drops a bad sample silently, DG:1285-1292.)
- * The flags of the last 256 calls are kept; reading a word clears it. */
+ * The flags of the last 256 calls are kept; reading a word clears it - the error is reported ONCE, so a caller that wants to
+ * go on must drop that batch when it gets the error (ofdg::DataGenerationLayer retires the buffer set before it throws).
+ * A word never speaks for another batch: once a caller has asked by ticket, a word whose last owner was not asked about
+ * is cleared in front of the first kernel of the call that takes it over (256 calls later), and a batch that was prepared
+ * ahead and discarded takes its flags with it. */
 long long ofdg_last_ticket(const ofdg_ctx* ctx);
 int ofdg_poll_errors_of(ofdg_ctx* ctx, long long ticket);
 
@@ -307,13 +311,10 @@ int ofdg_debug_coverage(ofdg_ctx* ctx, int sample, int shape, int frame,
 int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
 /* Number of raster work items the last launch left unprocessed (diagnostics: 0). */
 int ofdg_debug_item_count(ofdg_ctx* ctx);
-/* Experiment (tools/exp_graph.py): the kernels of one ofdg_forward_counter call on internal stream `chain`, captured into a
- * HIP graph with their parameters frozen (replays render the SAME batch into the same buffers), to compare one
- * hipGraphLaunch per step with the four launches of the product path on the real kernels. */
-int ofdg_debug_graph_capture(ofdg_ctx* ctx, int chain, long long first_index, int n_samples,
-                             float* d_image0, float* d_image1, float* d_flow, void** graph_exec);
-int ofdg_debug_graph_launch(ofdg_ctx* ctx, void* graph_exec, int chain);
-int ofdg_debug_graph_destroy(ofdg_ctx* ctx, void* graph_exec);
+/* After a render / forward call with background_prep = 1: the number of tiles the one-launch form of the preparation
+ * (bgprep_fused_kernel) walked for that batch and the number of workgroups that shared them grid-stride (0 tiles: the batch took
+ * another form of the preparation).  Tests use it to make sure they reach a workgroup's 2nd, 3rd ... tile. */
+int ofdg_debug_bgprep_tiles(ofdg_ctx* ctx, int* tiles, int* workgroups);
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract
  * [u*256+v] (DG:606, 626), AA mask byte [c], draw_image blend [d*256+m] for s=s_fixed. */
 int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl,
@@ -325,7 +326,12 @@ int ofdg_debug_detmath(ofdg_ctx* ctx, const double* angles, int n, double* sin_o
 /* Per-kernel device time (ms), averaged over the launches recorded since ofdg_set_profiling (mode 1: the compose launch
  * and the background preparation of every 4th batch, completion signals on the kernels' own packets, nothing added to the
  * streams; mode 2: every kernel of every batch, with start markers; 0: off).  Names: "geom", "raster" (mode 2), "compose",
- * "background_prep" (where the preparation runs behind raster: batches the library prepares itself). */
+ * "background_prep" (where the preparation runs behind raster: batches the library prepares itself).
+ * Mode 1 takes the compose launch's time from the completion of the chain's last preparation kernel to its own completion
+ * (no marker packet in the stream): only launches enqueued right behind their preparation on the chain's own stream are
+ * samples - a batch prepared ahead (ofdg_params.lookahead) or composed on a caller's stream is left out, since that span
+ * would hold host and queue idle time; with nothing but such launches ofdg_kernel_ms reports "no profiled launch".  Mode 2
+ * (start markers) times every launch. */
 int ofdg_set_profiling(ofdg_ctx* ctx, int mode);
 int ofdg_kernel_ms(ofdg_ctx* ctx, const char* kernel, float* ms);
 

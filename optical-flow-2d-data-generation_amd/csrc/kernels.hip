@@ -2004,8 +2004,9 @@ struct FuseTile {
   int fits;                 // ... which fit the LDS tile of C
   int inside;               // no mirroring / clamping anywhere in the tile: the per-texel range tests are skipped
 };
-__device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
-__device__ __forceinline__ int fuse_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kFuseW) / kFuseW; }
+__host__ __device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
+__host__ __device__ __forceinline__ int fuse_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kFuseW) / kFuseW; }
+__host__ __device__ __forceinline__ int fuse_tile_rows(const DevBgPrep& q) { return (q.ry1 - q.ry0 + kFuseH) / kFuseH; }
 // cimg_resize_range with the two table entries it reads already in hand (e0 = at[n * s + d0], e1 = at[n * s + d1])
 __device__ __forceinline__ void fuse_range(int n, int s, int d0, int d1, int e0, int e1, int* lo, int* hi) {
   if (s > n) { *lo = e0; *hi = min(e1 + 1, n - 1); }
@@ -2144,7 +2145,7 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
         const DevBgPrep& q = prep[i];
         const bool fits = fuse_sample_fits(q, cap_cw, cap_ch);
         if (!fits && blockIdx.x == 0) atomicOr(err, kErrBgPrepCapacity);
-        nt = fits ? fuse_tile_cols(q) * ((q.ry1 - q.ry0 + kFuseH) / kFuseH) : 0;
+        nt = fits ? fuse_tile_cols(q) * fuse_tile_rows(q) : 0;
       }
       const int incl = wave_scan_incl(nt);
       if (i < n_samples) s_first[i + 1] = running + incl;

@@ -243,10 +243,50 @@ bool is_png(const std::string& path) {
   static const unsigned char want[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   return f.gcount() == 8 && std::memcmp(sig, want, 8) == 0;
 }
+// libpng's simplified API hands out 8-bit sRGB samples: a 16-bit file is converted from linear light and a gAMA chunk that
+// is not sRGB's is honoured, while the reference's CImg::load (DataGenerator.cpp:128) keeps the raw sample values with no
+// gamma handling.  Such files would give the pool other bytes than the reference's: they are refused, by a walk over the
+// chunks in front of the image data (IHDR bit depth, gAMA), with the way out in the message.
+bool png_samples_are_raw_8bit(const std::string& path, std::string* why) {
+  std::ifstream f(path, std::ios::binary);
+  f.seekg(8);
+  auto be32 = [](const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; };
+  for (int guard = 0; guard < 4096; ++guard) {
+    unsigned char head[8];
+    f.read((char*)head, 8);
+    if (f.gcount() != 8) break;
+    const uint32_t len = be32(head);
+    const std::string type((const char*)head + 4, 4);
+    if (type == "IDAT" || type == "IEND") return true;
+    if (type == "IHDR" || type == "gAMA") {
+      unsigned char data[16] = {0};
+      const uint32_t take = len < 16 ? len : 16;
+      f.read((char*)data, take);
+      if ((uint32_t)f.gcount() != take) break;
+      if (type == "IHDR" && take >= 9 && data[8] == 16) {
+        *why = "16-bit PNG: libpng would convert its samples from linear light, the reference keeps raw values; convert the texture to 8 bit (tools/convert_textures.py)";
+        return false;
+      }
+      if (type == "gAMA" && take >= 4) {
+        const double g = be32(data) / 100000.0;  // file gamma; sRGB's is 1 / 2.2
+        if (g < 0.45455 * 0.95 || g > 0.45455 * 1.05) {
+          *why = "PNG with a gAMA chunk of " + std::to_string(g) + ": libpng would re-encode its samples, the reference keeps raw values; strip the chunk or convert the texture (tools/convert_textures.py)";
+          return false;
+        }
+      }
+      f.seekg((std::streamoff)(len - take) + 4, std::ios::cur);
+    } else {
+      f.seekg((std::streamoff)len + 4, std::ios::cur);
+    }
+  }
+  *why = "truncated PNG";
+  return false;
+}
 // planar_bgr == nullptr: the size only
 bool read_png(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w, int* h, std::string* why) {
   const PngApi& api = png_api();
   if (!api.ok) { *why = "libpng16 is not available on this system"; return false; }
+  if (!png_samples_are_raw_8bit(path, why)) return false;
   PngImage img;
   std::memset(&img, 0, sizeof(img));
   img.version = kPngImageVersion;
@@ -465,16 +505,22 @@ void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const st
     // wait for THIS set's event only: the batches behind it keep rendering
     if (hipEventSynchronize((hipEvent_t)ring_done_[(size_t)(consumed_ % P)]) != hipSuccess)
       throw std::runtime_error("DataGenerationLayer::Forward: hipEventSynchronize failed");
-    // THIS batch's device error flags (a flag raised by a younger batch still rendering is reported at that batch's own turn)
-    if (ofdg_poll_errors_of(ctx_, ring_ticket_[(size_t)(consumed_ % P)]) != OFDG_OK)
-      throw std::runtime_error(std::string("DataGenerationLayer::Forward: ") + ofdg_last_error(ctx_));
+    // THIS batch's device error flags (a flag raised by a younger batch still rendering is reported at that batch's own turn).
+    // The word is cleared by the read, so the error is reported once: a truncated batch is RETIRED before the exception
+    // leaves - its buffer set goes back to the ring and its successor starts rendering - so that a caller that catches the
+    // exception and calls Forward again gets the NEXT batch, never the bad one as a valid top (the reference drops a bad
+    // sample and leaves stale data in its batch slot, DG:1285-1292).
+    std::string bad;
+    if (ofdg_poll_errors_of(ctx_, ring_ticket_[(size_t)(consumed_ % P)]) != OFDG_OK) bad = ofdg_last_error(ctx_);
     float** set = &ring_[(size_t)(consumed_ % P) * 3];
-    for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
+    if (bad.empty())
+      for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
     ++consumed_;
     in_flight_ = 0;
     for (long long b = consumed_; b < produced_; ++b)
       if (hipEventQuery((hipEvent_t)ring_done_[(size_t)(b % P)]) == hipErrorNotReady) ++in_flight_;
     while (produced_ < consumed_ + P - 1) enqueue_next();
+    if (!bad.empty()) throw std::runtime_error("DataGenerationLayer::Forward: " + bad);
     return;
   }
   int rc = ofdg_forward(ctx_, top[0]->mutable_gpu_data(), top[1]->mutable_gpu_data(), top[2]->mutable_gpu_data(), nullptr);

@@ -148,6 +148,7 @@ struct ofdg_ctx {
       hipEvent_t* ev = nullptr;    // profiled launch: its event set
       hipStream_t stream = nullptr;  // where the preparation was enqueued
       long long ticket = -1;       // the batch's number (its error word)
+      bool ahead = false;          // prepared by an EARLIER call (look-ahead): the end of its preparation says nothing about when compose could start
     } prep;
   };
   static constexpr int kMaxChains = 8;
@@ -183,9 +184,16 @@ struct ofdg_ctx {
   // Device error flags, ONE WORD PER CALL: call number q ("ticket") raises its flags in word q mod kErrWords, so that a prefetch
   // ring can ask at a batch's hand-over whether THAT batch was truncated (ofdg_poll_errors_of) - the reference drops a bad
   // sample silently (DG:1285-1292).  A word is cleared when it is read; one that was never asked for is read by
-  // ofdg_synchronize / ofdg_poll_errors, or together with the call that takes the word over kErrWords calls later.
+  // ofdg_synchronize / ofdg_poll_errors.  For a caller that asks by ticket (a prefetch ring) a word must not carry what an
+  // EARLIER owner left in it - a look-ahead preparation that was discarded, a batch the caller never asked about: once
+  // anybody has asked by ticket, a word that was not read since its last use is cleared on the chain's stream in front of
+  // the first kernel of the call that takes it over (`word_clean`, launch_prepare).  A caller that only ever uses the
+  // device-wide forms (bench.py) pays nothing.  Word kErrWords belongs to the debug entry points.
   static constexpr int kErrWords = 256;
-  uint32_t* d_err = nullptr;     // [kErrWords]
+  uint32_t* d_err = nullptr;     // [kErrWords + 1]
+  bool asked_by_ticket = false;  // ofdg_poll_errors_of has been called on this context
+  bool word_clean[kErrWords];    // the word holds nothing of a call before the one that owns it now (all true at creation)
+  long long word_reserved = -1;  // the ticket whose word an upload's background preparation already writes into (ofdg_upload_slot)
   long long ticket = 0;          // calls made so far = the ticket of the next call
   // background_prep = 1: CImg's enlarging tables for every source length below 2W (x) / 2H (y), tabulated once
   DevBuf<uint16_t> d_bg_at_x, d_bg_at_y;
@@ -218,6 +226,16 @@ struct ofdg_ctx {
 
 // the error word of the call being made (its ticket is taken - c->ticket advanced - when the call's first kernel is enqueued)
 static uint32_t* err_word(ofdg_ctx* c, long long ticket) { return c->d_err + (size_t)(ticket % ofdg_ctx::kErrWords); }
+// The call with this ticket is about to enqueue its first kernel on `s`: what an earlier owner left in its word goes first
+// (only for callers that ask by ticket; see ofdg_ctx::word_clean).
+static hipError_t take_err_word(ofdg_ctx* c, long long ticket, hipStream_t s) {
+  const size_t i = (size_t)(ticket % ofdg_ctx::kErrWords);
+  hipError_t e = hipSuccess;
+  if (c->word_reserved == ticket) c->word_reserved = -1;  // (an upload for this very call already raised its flags here: they are this call's)
+  else if (c->asked_by_ticket && !c->word_clean[i]) e = hipMemsetAsync(c->d_err + i, 0, sizeof(uint32_t), s);
+  c->word_clean[i] = false;
+  return e;
+}
 static std::string err_text(uint32_t e) {
   std::string t = "device capacity exceeded:";
   if (e & kErrVertCapacity) t += " outline vertices > 1024;";
@@ -273,6 +291,7 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   e = hipSetDevice(params->device);
   if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return OFDG_EHIP; }
   std::unique_ptr<ofdg_ctx> c(new ofdg_ctx());
+  std::fill(c->word_clean, c->word_clean + ofdg_ctx::kErrWords, true);
   c->prm = *params;
   if (c->prm.world_size < 1) c->prm.world_size = 1;
   c->sampler.reset(new RefSampler(params->mode, params->width, params->height, params->num_objects));
@@ -317,8 +336,8 @@ int ofdg_create(const ofdg_params* params, ofdg_ctx** out) {
   }
   if ((e = hipMalloc((void**)&c->d_cs_tab, sizeof(tab))) != hipSuccess ||
       (e = hipMemcpy(c->d_cs_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMalloc((void**)&c->d_err, ofdg_ctx::kErrWords * sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMemset(c->d_err, 0, ofdg_ctx::kErrWords * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_err, (ofdg_ctx::kErrWords + 1) * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMemset(c->d_err, 0, (ofdg_ctx::kErrWords + 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->user_stage.free_ev, hipEventDisableTiming)) != hipSuccess) {
     g_create_error = std::string("HIP initialisation: ") + hipGetErrorString(e);
     return OFDG_EHIP;
@@ -890,6 +909,12 @@ static int discard_prepared(ofdg_ctx* c, ofdg_ctx::Chain& ch) {
   if (!ch.prep.valid) return OFDG_OK;
   ch.prep.valid = false;
   if (ch.prep.slot && ch.prep.slot->d_item_count) HIP_OK(c, hipMemsetAsync(ch.prep.slot->d_item_count, 0, sizeof(int), ch.prep.stream));
+  // ... and what its kernels flagged is nobody's: the batch is never handed over (its word must not speak for ticket + kErrWords,
+  // nor make ofdg_synchronize report a batch that was never composed)
+  if (ch.prep.ticket >= 0 && ch.prep.ticket + ofdg_ctx::kErrWords > c->ticket) {
+    HIP_OK(c, hipMemsetAsync(err_word(c, ch.prep.ticket), 0, sizeof(uint32_t), ch.prep.stream));
+    c->word_clean[(size_t)(ch.prep.ticket % ofdg_ctx::kErrWords)] = true;
+  }
   return OFDG_OK;
 }
 static int discard_all_prepared(ofdg_ctx* c) {
@@ -954,6 +979,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   }
   // mode 9: the batch's own crop table (host path) or the static table of all crops (counter sampler)
   const DevCropRef* croptab = cs_first_index >= 0 ? c->d_cs_croptab : sl.d_croptab.p;
+  HIP_OK(c, take_err_word(c, ticket, S));  // (nothing is enqueued unless this caller asks by ticket AND the word's last owner was never asked about)
   if (cs_first_index >= 0) {  // device counter sampler + device realize
     int rc = launch_counter_sampler(c, sl, cs_first_index, S, err);
     if (rc != OFDG_OK) return rc;
@@ -997,6 +1023,7 @@ static int launch_prepare(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl, 
   if (ev && hand_over) HIP_OK(c, hipEventRecord(ch.ev_prep, S));
   ch.prep.valid = true; ch.prep.slot = &sl; ch.prep.first_index = cs_first_index; ch.prep.n = sl.res_samples;
   ch.prep.box_cur = box_cur; ch.prep.croptab = croptab; ch.prep.ev = ev; ch.prep.stream = S; ch.prep.ticket = ticket;
+  ch.prep.ahead = false;
   return OFDG_OK;
 }
 
@@ -1057,8 +1084,14 @@ static int launch_compose(ofdg_ctx* c, ofdg_ctx::Chain& ch, float* d_img0, float
   HIP_OK(c, hipGetLastError());
   if (ev) {
     if (done) HIP_OK(c, hipEventRecord(done, CS));
-    c->ev_count++;
-    c->ev_composed[(size_t)(ev - c->ev.data()) / 6] = 1;
+    // profiling 1 times compose from the completion of the chain's last preparation kernel: that is the launch's time only
+    // when compose is enqueued right behind it on the same stream.  A batch prepared ahead by an earlier call, or composed
+    // on a caller's stream behind the hand-over event, would count host and queue idle time: such a set is not a sample.
+    const bool span_is_the_launch = c->profiling == 2 || (!foreign && !ch.prep.ahead);
+    if (span_is_the_launch) {
+      c->ev_count++;
+      c->ev_composed[(size_t)(ev - c->ev.data()) / 6] = 1;
+    }
   }
   if (done) {
     sl.compose_pending = true; sl.compose_stream = CS; sl.compose_event = done;
@@ -1080,6 +1113,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
 
 // CImg get_resize(.., 3), enlarging branch: source index and weight of every destination pixel (running double sums,
 // boundary 0) for EVERY source length n < s, entry [n * s + x]; once per context and frame size
+constexpr int kBgPrepFusedBlocks = 2048;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
 static int ensure_bgprep_tables(ofdg_ctx* c) {
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
   if (c->bg_tab_w == TW && c->bg_tab_h == TH) return OFDG_OK;
@@ -1125,7 +1159,6 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
   bgprep_caps(c, &cap_cw, &cap_ch, &fusable);
   const bool staged = c->prm.background_prep == 1;
   constexpr int kBgPrepBlocks = 192;  // x 256 threads per sample, grid-stride over the (device-known) region
-  constexpr int kBgPrepFusedBlocks = 2048;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
   if (staged) {
     int rct = ensure_bgprep_tables(c);
     if (rct != OFDG_OK) return rct;
@@ -1248,7 +1281,9 @@ static int upload_slot(ofdg_ctx* c, ofdg_ctx::Slot& sl, const ofdg_task* tasks, 
   }
   if (c->prm.background_prep) {
     if (shared) {  // a caller's slot is prepared once, here, and rendered any number of times
-      int rcb = prepare_backgrounds(c, sl, n_tasks, /*records_resident=*/true, st, err_word(c, c->ticket));  // (the word of the call that renders this batch next)
+      // (flags go into the word of the call that renders this batch next; that call must not clear them: word_reserved)
+      if (c->word_reserved != c->ticket) { HIP_OK(c, take_err_word(c, c->ticket, st)); c->word_reserved = c->ticket; }
+      int rcb = prepare_backgrounds(c, sl, n_tasks, /*records_resident=*/true, st, err_word(c, c->ticket));
       if (rcb != OFDG_OK) return rcb;
       sl.bgprep_pending = false;
     } else {
@@ -1384,6 +1419,7 @@ int ofdg_forward_counter(ofdg_ctx* c, long long first_index, int n_samples, floa
       // a preparation ahead that cannot be enqueued is dropped: the call that needs the batch prepares it itself and
       // reports the failure if it persists
       if (prepare_on(cj, first_index + (long long)d * stride, cj.stream, true) != OFDG_OK) { (void)discard_prepared(c, cj); break; }
+      cj.prep.ahead = true;
     }
   }
   return OFDG_OK;
@@ -1509,8 +1545,9 @@ int ofdg_synchronize(ofdg_ctx* c, void* stream) {
       const long long q = c->ticket - 1 - ((c->ticket - 1 - i) % ofdg_ctx::kErrWords + ofdg_ctx::kErrWords) % ofdg_ctx::kErrWords;
       if (first_bad < 0 || q < first_bad) first_bad = q;
     }
+  if (e) HIP_OK(c, hipMemset(c->d_err, 0, sizeof(words)));
+  if (c->word_reserved < 0) std::fill(c->word_clean, c->word_clean + ofdg_ctx::kErrWords, true);  // (nothing in flight, every word read)
   if (e) {
-    HIP_OK(c, hipMemset(c->d_err, 0, sizeof(words)));
     c->err = err_text(e) + " (first in batch " + std::to_string(first_bad) + " of this context, or one " + std::to_string(ofdg_ctx::kErrWords) + " calls earlier)";
     return OFDG_ECAPACITY;
   }
@@ -1549,8 +1586,10 @@ int ofdg_poll_errors_of(ofdg_ctx* c, long long ticket) {
   if (!c) return OFDG_EINVAL;
   if (ticket < 0 || ticket >= c->ticket || ticket + ofdg_ctx::kErrWords <= c->ticket) { c->err = "ofdg_poll_errors_of: no such batch (tickets of the last " + std::to_string(ofdg_ctx::kErrWords) + " calls are kept)"; return OFDG_EINVAL; }
   uint32_t e = 0;
+  c->asked_by_ticket = true;
   int rc = poll_words(c, (int)(ticket % ofdg_ctx::kErrWords), 1, &e);
   if (rc != OFDG_OK) return rc;
+  c->word_clean[(size_t)(ticket % ofdg_ctx::kErrWords)] = true;  // (read and cleared; the caller waited for this batch before asking)
   if (e) { c->err = "batch " + std::to_string(ticket) + ": " + err_text(e); return OFDG_ECAPACITY; }
   return OFDG_OK;
 }
@@ -1744,13 +1783,18 @@ int ofdg_debug_rasterize_path(ofdg_ctx* c, const double* xy, const int* types, i
   HIP_OK(c, hipMemcpy(d_xy, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(d_ty, types, sizeof(int) * n, hipMemcpyHostToDevice));
   HIP_OK(c, hipMemset(d_v, 0, sizeof(int2) * kMaxVerts));
-  hipLaunchKernelGGL(debug_path_kernel, dim3(1), dim3(64), 0, 0, d_xy, d_ty, n, d_v, d_n, c->d_err);
+  uint32_t* const dbg_err = c->d_err + ofdg_ctx::kErrWords;  // (the debug entry points' own word: no batch inherits it)
+  hipLaunchKernelGGL(debug_path_kernel, dim3(1), dim3(64), 0, 0, d_xy, d_ty, n, d_v, d_n, dbg_err);
   HIP_OK(c, hipGetLastError());
+  uint32_t dbg_flags = 0;
+  HIP_OK(c, hipMemcpy(&dbg_flags, dbg_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (dbg_flags) HIP_OK(c, hipMemset(dbg_err, 0, sizeof(uint32_t)));
   std::vector<int2> v(kMaxVerts);
   int nv = 0;
   HIP_OK(c, hipMemcpy(v.data(), d_v, sizeof(int2) * kMaxVerts, hipMemcpyDeviceToHost));
   HIP_OK(c, hipMemcpy(&nv, d_n, sizeof(int), hipMemcpyDeviceToHost));
   (void)hipFree(d_xy); (void)hipFree(d_ty); (void)hipFree(d_v); (void)hipFree(d_n);
+  if (dbg_flags) { c->err = "debug_rasterize_path: " + err_text(dbg_flags); return OFDG_ECAPACITY; }
   if (nv < 1 || nv > kMaxVerts) { c->err = "debug_rasterize_path: the flattened outline has " + std::to_string(nv) + " vertices"; return OFDG_ECAPACITY; }
   return debug_rasterize_verts(c, v, nv, coverage_host);
 }
@@ -1804,49 +1848,24 @@ int ofdg_debug_item_count(ofdg_ctx* c) {
   return n;
 }
 
-// ---- a step as ONE submission (inspection / experiment: tools/exp_graph.py) ----------------------------------
-// The kernels of one ofdg_forward_counter call - [counter sampler -> background preparation ->] geom -> raster -> compose -
-// captured from chain `chain`'s stream into a HIP graph with its parameters FROZEN (first_index, the output buffers, the
-// block-mask parity, the batch's error word), so that replays render the same batch again: enough to measure what the
-// submission form costs on the host and on the device with the real kernels, not a way to render new samples (the sampler's
-// first index, the mask parity and the error word change from step to step: a product graph would have to keep them in a
-// device-resident step record that every kernel reads at its start).
-int ofdg_debug_graph_capture(ofdg_ctx* c, int chain, long long first_index, int n_samples, float* d_img0, float* d_img1, float* d_flow,
-                             void** graph_exec) {
-  if (!c || !graph_exec || chain < 0 || chain >= c->n_chains || !d_img0 || !d_img1 || !d_flow || first_index < 0) return OFDG_EINVAL;
-  if (c->prm.sampler != OFDG_SAMPLER_COUNTER || !c->overlap || c->profiling) { c->err = "graph capture: counter sampler, chains and no profiling"; return OFDG_EINVAL; }
-  ofdg_ctx::Chain& ch = c->chains[chain];
+// How bgprep_fused_kernel walked the last batch: the number of its tiles (only known on the device: a sample's read region
+// depends on its background motion) and of the workgroups that shared them grid-stride - a test that means to compare the
+// SECOND, third ... tile of a workgroup with the oracle asserts tiles > k * workgroups.  0 tiles: the batch took another form
+// of the preparation (background_prep != 1, pool images smaller than 2W x 2H, more samples than the fused form numbers).
+int ofdg_debug_bgprep_tiles(ofdg_ctx* c, int* tiles, int* workgroups) {
+  if (!c || !tiles || !workgroups || !c->last_slot) return OFDG_EINVAL;
+  const ofdg_ctx::Slot& sl = *c->last_slot;
+  *tiles = 0; *workgroups = kBgPrepFusedBlocks;
+  int cap_cw, cap_ch;
+  bool fusable;
+  bgprep_caps(c, &cap_cw, &cap_ch, &fusable);
+  const int n = sl.res_samples;
+  if (c->prm.background_prep != 1 || !fusable || n > kFuseMaxSamples || n < 1 || !sl.d_bgprep.p) return OFDG_OK;
   HIP_OK(c, hipDeviceSynchronize());
-  { int rcd = discard_prepared(c, ch); if (rcd != OFDG_OK) return rcd; }
-  // every allocation happens before the capture starts (and once more, so that the tables of the preparation exist)
-  int rc = prepare_counter_slot(c, ch.slot, n_samples);
-  if (rc == OFDG_OK && c->prm.background_prep == 1) rc = ensure_bgprep_tables(c);
-  if (rc != OFDG_OK) return rc;
-  HIP_OK(c, hipDeviceSynchronize());
-  hipGraph_t g = nullptr;
-  HIP_OK(c, hipStreamBeginCapture(ch.stream, hipStreamCaptureModeThreadLocal));
-  rc = launch_prepare(c, ch, ch.slot, ch.stream, first_index, false);
-  if (rc == OFDG_OK) rc = launch_compose(c, ch, d_img0, d_img1, d_flow, ch.stream);
-  const hipError_t e = hipStreamEndCapture(ch.stream, &g);
-  // (the block-mask parity is frozen with the rest: capture TWO graphs per chain and replay them alternately - as bench.py's
-  //  two buffer sets per chain do - and each clears the masks the other marks, like consecutive launches)
-  if (rc != OFDG_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-  if (e != hipSuccess) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return OFDG_EHIP; }
-  hipGraphExec_t ge = nullptr;
-  HIP_OK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-  HIP_OK(c, hipGraphDestroy(g));
-  *graph_exec = (void*)ge;
-  return OFDG_OK;
-}
-int ofdg_debug_graph_launch(ofdg_ctx* c, void* graph_exec, int chain) {
-  if (!c || !graph_exec || chain < 0 || chain >= c->n_chains) return OFDG_EINVAL;
-  HIP_OK(c, hipGraphLaunch((hipGraphExec_t)graph_exec, c->chains[chain].stream));
-  return OFDG_OK;
-}
-int ofdg_debug_graph_destroy(ofdg_ctx* c, void* graph_exec) {
-  if (!c || !graph_exec) return OFDG_EINVAL;
-  HIP_OK(c, hipDeviceSynchronize());
-  HIP_OK(c, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  std::vector<DevBgPrep> rec((size_t)n);
+  HIP_OK(c, hipMemcpy(rec.data(), sl.d_bgprep.p, rec.size() * sizeof(DevBgPrep), hipMemcpyDeviceToHost));
+  for (const DevBgPrep& q : rec)
+    if (fuse_sample_fits(q, cap_cw, cap_ch)) *tiles += fuse_tile_cols(q) * fuse_tile_rows(q);
   return OFDG_OK;
 }
 

@@ -42,6 +42,24 @@ def test_launcher_exits_non_zero_when_a_rank_does():
     assert "rank 1 exited with 5" in r.stderr
 
 
+def test_launcher_drains_its_children_while_they_run():
+    """A rank that prints more than a pipe holds (64 KB) must not block on the launcher: its output is read while it runs."""
+    r = run(["--gpus", "2", "--launch-only"], OFDG_BENCH_TEST_PAD="300000")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert [k["rank"] for k in d["ranks"]] == [0, 1]
+
+
+def test_launcher_starts_again_when_the_port_was_taken():
+    """The rendezvous port is probed by the launcher and bound by rank 0 later: when somebody takes it in between, rank 0 exits
+    with bench.EXIT_PORT_TAKEN and the launcher repeats the whole start on another port."""
+    r = run(["--gpus", "2", "--launch-only"], OFDG_BENCH_TEST_PORT_TAKEN="1")
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert "starting again on another one" in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert [k["rank"] for k in d["ranks"]] == [0, 1]
+
+
 def test_the_parent_does_not_touch_the_gpu_stack():
     """The launcher must not import torch (let alone torch.cuda) or load libofdg.so: its children initialise the GPU."""
     code = ("import sys, runpy\n"

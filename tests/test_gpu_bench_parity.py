@@ -1,0 +1,136 @@
+"""What bench.py TIMES, compared with the oracle (VERDICT r04 "next" #1).
+
+The workloads are bench.CONFIGS themselves (imported: no second copy of the numbers), with the background preparation
+the headline runs (background_prep = 1, Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift), DataGenerator.cpp:87-109,
+1186-1192), the pool bench.py builds (same size, same seed), the seed bench.py uses, one rank's whole batch rendered the
+way a bench step renders it (ofdg_forward_counter on the context's own stream) - and the first sample, one from the middle
+and the LAST TWO samples of the batch compared with oracle.render under oracle.detmath(): frames 0 LSB, flow <= 1 ULP.
+
+Why the last samples: the one-launch form of the preparation (bgprep_fused_kernel) hands the batch's tiles to a fixed
+number of workgroups grid-stride, so tile numbers beyond that number are a workgroup's SECOND, third ... tile - the
+software-pipelined part of its loop (the next tile's placement and table entries carried over from the previous turn).
+The tiles of the last samples have the highest numbers; every test asserts through ofdg_debug_bgprep_tiles that the batch
+holds more than three times as many tiles as there are workgroups, so that the property cannot lapse silently when a grid
+constant changes.  (Config 4 is 8 samples of 1024 x 768 per rank: the same tile count as 32 of 512 x 384.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def blueprints_of(task, bps):
+    """indices of every blueprint a task refers to (background, objects, their components)"""
+    used = [task.background] + list(range(task.first_object, task.first_object + task.n_objects))
+    for k in range(task.n_objects):
+        b = bps[task.first_object + k]
+        used += list(range(b.first_component, b.first_component + b.n_components))
+    return used
+
+
+def check_samples(ofdg, oracle, g, prm, tasks, bps, n_bps, got, which, pool_n, crops=None):
+    """Samples `which` of a rendered batch against the oracle.  The oracle gets a host pool of just the images those samples
+    use (texture ids re-indexed: tex_id % len(images) picks the same image in the small pool)."""
+    W, H = prm.width, prm.height
+    i0, i1, fl = got
+    for sidx in which:
+        t = tasks[sidx]
+        used = blueprints_of(t, bps)
+        images = sorted({bps[i].tex_id % pool_n for i in used})
+        host_pool = np.stack([g.pool_download(i) for i in images])
+        sub = (ofdg.Blueprint * n_bps)()
+        C.memmove(sub, bps, C.sizeof(sub))
+        for i in used:
+            sub[i].tex_id = images.index(bps[i].tex_id % pool_n)
+        q = oracle.default_params(W, H, prm.mode, prm.use_antialiasing, 1, prm.num_objects)
+        q.background_prep = prm.background_prep
+        with oracle.detmath():  # the device sampler builds its affines and the preparation record with include/ofdg_detmath.h
+            e0, e1, ef = oracle.render(q, (ofdg.Task * 1)(t), 1, sub, n_bps, host_pool, warp_crops=crops, reuse=-1)
+        a0, a1, af = i0[sidx].cpu().numpy(), i1[sidx].cpu().numpy(), fl[sidx].cpu().numpy()
+        assert np.array_equal(a0, e0[0]), "sample %d image0: %d values differ, max %g" % (sidx, (a0 != e0[0]).sum(), np.abs(a0 - e0[0]).max())
+        assert np.array_equal(a1, e1[0]), "sample %d image1: %d values differ, max %g" % (sidx, (a1 != e1[0]).sum(), np.abs(a1 - e1[0]).max())
+        assert np.array_equal(np.isnan(af), np.isnan(ef[0]))
+        ok = ~np.isnan(ef[0])
+        assert ulp_diff(af[ok], ef[0][ok]).max() <= 1, "sample %d flow" % sidx
+
+
+def bench_generator(ofdg, bench, cfg, sampler):
+    W, H, B = cfg["W"], cfg["H"], cfg["batch"]
+    prm = ofdg.default_params(width=W, height=H, mode=cfg["mode"], num_objects=cfg["nobj"], batch_size=B, sampler=sampler,
+                              seed=bench.SEED, background_prep=1)
+    g = ofdg.Generator(prm)
+    g.pool_synthetic(*cfg["pool"], bench.POOL_SEED)
+    crops = None
+    if cfg["mode"] == 9:
+        g.warp_generate(2, bench.SEED)
+        crops = np.stack([g.warp_download(i) for i in range(g.warp_count())])
+    return g, prm, crops
+
+
+def assert_tiles_beyond_the_grid(g, k=3):
+    tiles, groups = g.debug_bgprep_tiles()
+    assert tiles > k * groups, "the batch's %d tiles do not reach a workgroup's tile %d (%d workgroups): this test no longer checks the tile loop" % (tiles, k + 1, groups)
+    return tiles, groups
+
+
+@pytest.mark.parametrize("config", [2, 3, 4, 5])
+def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, config):
+    """One rank's batch of BASELINE configs 2-5 exactly as `python bench.py --config N` renders its steps (counter sampler,
+    background_prep = 1, the config's pool): first, middle and last two samples at 0 LSB / <= 1 ULP, and the batch is
+    large enough to take every workgroup of the preparation through more than three tiles."""
+    import bench
+    torch = pytest.importorskip("torch")
+    cfg = bench.CONFIGS[config]
+    B = cfg["batch"]
+    g, prm, crops = bench_generator(ofdg, bench, cfg, sampler=1)
+    got = ofdg.alloc_outputs(B, cfg["H"], cfg["W"])
+    first = 2 * B   # (step 2 of rank 0: any step is a pure function of (seed, index))
+    g.forward_counter(first, B, *got, ofdg.STREAM_OWN)
+    g.synchronize()
+    torch.cuda.synchronize()
+    assert_tiles_beyond_the_grid(g)
+    tasks, bps, n = g.sample_counter(first, B)
+    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, sorted({0, B // 2, B - 2, B - 1}), cfg["pool"][0], crops)
+    g.close()
+
+
+def test_host_sampled_batch_with_background_preparation_matches_oracle(ofdg, oracle):
+    """The same for the host-sampled path (ofdg_render: reference-stream blueprints realised on the host, the preparation's
+    records uploaded with the batch, the preparation behind raster): config 2's shape, 32 samples of 512 x 384."""
+    import bench
+    cfg = bench.CONFIGS[2]
+    W, H, B = cfg["W"], cfg["H"], cfg["batch"]
+    g, prm, _ = bench_generator(ofdg, bench, cfg, sampler=0)
+    tasks, bps, n = oracle.Sampler(cfg["mode"], W, H, cfg["nobj"]).next(B)
+    got = ofdg.alloc_outputs(B, H, W)
+    g.render(tasks, B, bps, n, *got)
+    g.synchronize()
+    assert_tiles_beyond_the_grid(g)
+    pool_n = cfg["pool"][0]
+    i0, i1, fl = got
+    for sidx in (0, B // 2, B - 2, B - 1):
+        t = tasks[sidx]
+        used = blueprints_of(t, bps)
+        images = sorted({bps[i].tex_id % pool_n for i in used})
+        host_pool = np.stack([g.pool_download(i) for i in images])
+        sub = (ofdg.Blueprint * n)()
+        C.memmove(sub, bps, C.sizeof(sub))
+        for i in used:
+            sub[i].tex_id = images.index(bps[i].tex_id % pool_n)
+        q = oracle.default_params(W, H, cfg["mode"], 1, 1, cfg["nobj"])
+        q.background_prep = 1
+        e0, e1, ef = oracle.render(q, (ofdg.Task * 1)(t), 1, sub, n, host_pool)  # (libm arithmetic: the host path's own)
+        assert np.array_equal(i0[sidx].cpu().numpy(), e0[0]), "sample %d image0" % sidx
+        assert np.array_equal(i1[sidx].cpu().numpy(), e1[0]), "sample %d image1" % sidx
+        assert ulp_diff(fl[sidx].cpu().numpy(), ef[0]).max() == 0, "sample %d flow" % sidx
+    g.close()

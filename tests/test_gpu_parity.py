@@ -1082,11 +1082,57 @@ def test_device_error_is_reported_at_its_own_batch(ofdg, oracle):
     assert e.value.code == ofdg.ECAPACITY
 
 
+def test_an_error_word_never_speaks_for_another_batch(ofdg, oracle):
+    """The 256 error words go round.  A batch whose flag nobody asked about by ticket must not make the batch that takes its
+    word over, 256 calls later, look truncated to a caller that does ask by ticket (a prefetch ring): the word is cleared in
+    front of that call's first kernel.  The device-wide check (ofdg_synchronize) still reports such a flag while it is there."""
+    torch = torch_mod()
+    W, H, B = 64, 48, 1
+    g = make_gen(ofdg, W, H, 5, num_objects=4)
+    smp = oracle.Sampler(5, W, H, 4)
+    good = smp.next(B)
+    bad = victim = None
+    for _ in range(50):                       # a batch with a curved polygon to overflow the flattening with
+        t, b, nb = smp.next(B)
+        for k in range(t[0].n_objects):
+            o = b[t[0].first_object + k]
+            if o.obj_type == ofdg.OBJ_POLYGON and any(o.segment_type[i] == ofdg.SEG_CURVE3 for i in range(o.n_segments)):
+                bad, victim = (t, b, nb), o
+                break
+        if bad:
+            break
+    assert bad is not None
+    victim.scale = 600.0
+    out = ofdg.alloc_outputs(B, H, W)
+    g.render(good[0], B, good[1], good[2], *out)
+    torch.cuda.synchronize()
+    g.poll_errors_of(g.last_ticket())         # this caller asks by ticket
+    g.render(bad[0], B, bad[1], bad[2], *out)
+    t_bad = g.last_ticket()                   # ... but never about this one
+    for _ in range(255):
+        g.render(good[0], B, good[1], good[2], *out)
+    torch.cuda.synchronize()
+    g.render(good[0], B, good[1], good[2], *out)
+    assert g.last_ticket() == t_bad + 256     # the same word
+    torch.cuda.synchronize()
+    g.poll_errors_of(g.last_ticket())         # clean: the stale flag went before this call's first kernel
+    g.synchronize()
+    # without a by-ticket caller nothing is cleared behind anybody's back: the device-wide form reports the old flag
+    g2 = make_gen(ofdg, W, H, 5, num_objects=4)
+    g2.render(bad[0], B, bad[1], bad[2], *out)
+    for _ in range(256):
+        g2.render(good[0], B, good[1], good[2], *out)
+    with pytest.raises(ofdg.OfdgError) as e:
+        g2.synchronize()
+    assert e.value.code == ofdg.ECAPACITY
+
+
 def test_background_prep_batches_beyond_one_wave_of_samples(ofdg, oracle):
     """bgprep_fused_kernel numbers the tiles of all samples through a prefix of their tile counts that wave 0 builds 64 samples
-    at a time: a batch of 150 samples (three rounds of the prefix, tiles of late samples reached by grid-stride) renders like
-    the oracle, through the host-sampled path (records uploaded with the batch, the preparation behind raster) and through
-    the device sampler."""
+    at a time: a batch of 150 samples (three rounds of the prefix) renders like the oracle, through the host-sampled path
+    (records uploaded with the batch, the preparation behind raster) and through the device sampler.  (At most 1 800 tiles of
+    a 128 x 96 texture: every workgroup takes ONE tile here.  A workgroup's second and later tiles - the grid-stride part of
+    its loop - are compared with the oracle in tests/test_gpu_bench_parity.py, on the batches bench.py times.)"""
     W, H, B = 64, 48, 150
     p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1, sampler=1, seed=31, num_objects=3)
     g = ofdg.Generator(p)

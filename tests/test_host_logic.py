@@ -467,3 +467,26 @@ def test_native_image_decode_png_and_ppm(ofdg, tmp_path):
     with pytest.raises(ofdg.OfdgError) as e:
         ofdg.decode_image(p)
     assert e.value.code == ofdg.ETEXTURES
+    # PNGs whose samples libpng's 8-bit sRGB output would NOT hand over as stored (the reference's CImg::load keeps raw values,
+    # DataGenerator.cpp:128): a gAMA chunk that is not sRGB's, 16 bits per sample - refused, with the way out in the message;
+    # sRGB's own gamma (what most writers put there) changes nothing and decodes
+    import struct
+    from PIL import PngImagePlugin
+
+    def with_gamma(g):
+        info = PngImagePlugin.PngInfo()
+        info.add(b"gAMA", struct.pack(">I", int(round(g * 100000))))
+        return info
+    p = tmp_path / "h.png"
+    Image.fromarray(rgb).save(p, pnginfo=with_gamma(1.0))
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.decode_image(p)
+    assert e.value.code == ofdg.ETEXTURES and "gAMA" in str(e.value) and "convert_textures" in str(e.value)
+    p = tmp_path / "i.png"
+    Image.fromarray(rgb).save(p, pnginfo=with_gamma(0.45455))
+    assert np.array_equal(ofdg.decode_image(p), want)
+    p = tmp_path / "j.png"
+    Image.fromarray((grey.astype(np.uint16) * 257)).save(p)                # mode I;16
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.decode_image(p)
+    assert e.value.code == ofdg.ETEXTURES and "16-bit" in str(e.value)

@@ -5,7 +5,7 @@ set -e
 rev=$1; name=$2
 root="$(cd "$(dirname "$0")/.." && pwd)"
 pkg=optical-flow-2d-data-generation_amd
-tmp=$root/$pkg/build/rev_$name
+tmp=${TMPDIR:-/tmp}/ofdg_rev_$name   # (outside the package: the snapshot that travels to the GPU box holds no second copy of the sources)
 rm -rf $tmp; mkdir -p $tmp
 git -C $root archive $rev $pkg/csrc include | tar -x -C $tmp
 cd $tmp/$pkg

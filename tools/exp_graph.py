@@ -6,7 +6,8 @@ kernels captured with frozen parameters (ofdg_debug_graph_capture: replays rende
   launches, same batches    gen.forward_counter(first index of (chain, buffer set)): the graph arm's work, submitted by launches
   graphs, same batches      one hipGraphLaunch per step
 Host time to issue a step and wall time per step, for the driver's run length (20 steps from an idle device, median of REPS)
-and a long run.  Usage on the GPU box: python3 tools/exp_graph.py [reps]"""
+and a long run.  Needs a library built with tools/patches/r04_graph_capture.patch (the capture entry points are an experiment,
+not part of the product's C-ABI).  Usage on the GPU box: python3 tools/exp_graph.py [reps]"""
 import ctypes as C, importlib, os, statistics, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -537,13 +537,13 @@ def main():
             "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
         }
         if prep_ms is not None:
-            # The step's other heavy kernel is bound by neither HBM nor MFMA (gather latency when alone, the
-            # time its workgroups hold their LDS in the pipeline); reported: its launch, and its vector instructions against
+            # The step's other heavy kernel is bound by neither HBM nor MFMA (the latency of a wave's dependent chain - gathers, LDS, stores - per tile, and
+            # what the co-running kernels leave of the memory pipeline); reported: its launch, and its vector instructions against
             # the chip's issue rate - 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz - as a utilisation.
             # Instruction counts per launch come from the committed PMC pass of this configuration (null without one).
             valu = prep_pmc.get("valu_instructions_per_launch") if prep_pmc else None
             out["background_prep_kernel"] = {
-                "kernel": (prep_pmc or {}).get("kernel", "bgprep_fused_kernel"), "bound": "latency / LDS residency (neither hbm nor mfma)",
+                "kernel": (prep_pmc or {}).get("kernel", "bgprep_stream_kernel"), "bound": "latency of a wave's dependent chain per tile (neither hbm nor mfma)",
                 "kernel_ms": prep_ms, "kernel_ms_alone": alone["background_prep"],
                 "valu_instructions_per_launch": valu, "peak": VALU_PEAK_GINST, "unit": "G wave instructions/s",
                 "achieved": valu / (prep_ms * 1e-3) / 1e9 if valu else None,

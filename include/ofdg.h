@@ -312,7 +312,7 @@ int ofdg_debug_num_shapes(ofdg_ctx* ctx, int sample);
 /* Number of raster work items the last launch left unprocessed (diagnostics: 0). */
 int ofdg_debug_item_count(ofdg_ctx* ctx);
 /* After a render / forward call with background_prep = 1: the number of tiles the one-launch form of the preparation
- * (bgprep_fused_kernel) walked for that batch and the number of workgroups that shared them grid-stride (0 tiles: the batch took
+ * (bgprep_stream_kernel) walked for that batch and the number of workgroups that shared them grid-stride (0 tiles: the batch took
  * another form of the preparation).  Tests use it to make sure they reach a workgroup's 2nd, 3rd ... tile. */
 int ofdg_debug_bgprep_tiles(ofdg_ctx* ctx, int* tiles, int* workgroups);
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract

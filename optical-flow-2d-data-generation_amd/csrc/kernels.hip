@@ -1794,6 +1794,23 @@ __device__ __forceinline__ RotPair bgprep_rot_coords(const DevBgPrep& p, float x
 __device__ __forceinline__ bool bgprep_shift_plain(const DevBgPrep& p) { return p.shx >= 0 && p.shx <= p.pw && p.shy >= 0 && p.shy <= p.ph; }
 // Both texels lie inside [0, pw - 1) x [0, ph - 1) of the rotated image's source coordinates (mod, mirror and the Neumann
 // clamp are identities, x + 1 and y + 1 exist) and the shift is plain (0 <= shift <= size).
+// the strict-fp32 bilinear form of bgprep_rot_sample for two texels at once (taps cc / nc / cn / nn of texel 0 and 1, their
+// fractions as float pairs): Icc + dx*(Inc - Icc + dy*(Icc + Inn - Icn - Inc)) + dy*(Icn - Icc), truncated to u8 per channel
+__device__ __forceinline__ uint2 rot_blend2(uint32_t cc0, uint32_t nc0, uint32_t cn0, uint32_t nn0, uint32_t cc1, uint32_t nc1, uint32_t cn1, uint32_t nn1,
+                                            f32x2 dx, f32x2 dy) {
+  uint2 out = make_uint2(0, 0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int b = 8 * c;
+    const f32x2 Icc = {(float)((cc0 >> b) & 255u), (float)((cc1 >> b) & 255u)}, Inc = {(float)((nc0 >> b) & 255u), (float)((nc1 >> b) & 255u)};
+    const f32x2 Icn = {(float)((cn0 >> b) & 255u), (float)((cn1 >> b) & 255u)}, Inn = {(float)((nn0 >> b) & 255u), (float)((nn1 >> b) & 255u)};
+    const f32x2 t = ((Icc + Inn) - Icn) - Inc;
+    const f32x2 val = (Icc + dx * ((Inc - Icc) + dy * t)) + dy * (Icn - Icc);
+    out.x |= (uint32_t)(unsigned char)val.x << b;
+    out.y |= (uint32_t)(unsigned char)val.y << b;
+  }
+  return out;
+}
 template <class PairFn>
 __device__ __forceinline__ uint2 bgprep_rot_inside2_t(const DevBgPrep& p, const RotPair& r, bool second, PairFn pair) {
   const f32x2 mx = r.mx, my = r.my;
@@ -1816,19 +1833,7 @@ __device__ __forceinline__ uint2 bgprep_rot_inside2_t(const DevBgPrep& p, const 
   uint32_t cc0, nc0, cn0, nn0, cc1 = 0, nc1 = 0, cn1 = 0, nn1 = 0;
   row_pair(x0i, sh(y0i, p.shy), sh(y0i + 1, p.shy), &cc0, &nc0, &cn0, &nn0);
   if (second) row_pair(x1i, sh(y1i, p.shy), sh(y1i + 1, p.shy), &cc1, &nc1, &cn1, &nn1);
-  uint2 out = make_uint2(0, 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int b = 8 * c;
-    const f32x2 Icc = {(float)((cc0 >> b) & 255u), (float)((cc1 >> b) & 255u)}, Inc = {(float)((nc0 >> b) & 255u), (float)((nc1 >> b) & 255u)};
-    const f32x2 Icn = {(float)((cn0 >> b) & 255u), (float)((cn1 >> b) & 255u)}, Inn = {(float)((nn0 >> b) & 255u), (float)((nn1 >> b) & 255u)};
-    // Icc + dx*(Inc - Icc + dy*(Icc + Inn - Icn - Inc)) + dy*(Icn - Icc)
-    const f32x2 t = ((Icc + Inn) - Icn) - Inc;
-    const f32x2 val = (Icc + dx * ((Inc - Icc) + dy * t)) + dy * (Icn - Icc);
-    out.x |= (uint32_t)(unsigned char)val.x << b;
-    out.y |= (uint32_t)(unsigned char)val.y << b;
-  }
-  return out;
+  return rot_blend2(cc0, nc0, cn0, nn0, cc1, nc1, cn1, nn1, dx, dy);
 }
 // ... with the taps fetched from the pool image in memory
 __device__ __forceinline__ uint2 bgprep_rot_inside2(const DevBgPrep& p, const RotPair& r, bool second) {
@@ -1971,54 +1976,55 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 }
 
 // ---- the same chain in ONE launch (pool images at least 2W x 2H: a crop is at most 4/3 of the texture) ------------------
-// A workgroup renders kFuseW x kFuseH tiles of B.  Per tile: the texels of C the tile needs (cimg_resize_range of its
-// columns and rows: at most 4/3 of the tile + 2 each way) are sampled into LDS; M = X-resize of C overwrites C's rows in
-// place (a row belongs to ONE wave: its lanes read the row's texels before any of them writes); B = Y-resize of M goes to
-// memory.  C and M never leave the CU, the per-column table entries are loaded once per tile instead of once per texel,
-// and the two launches (with the round trip of C through HBM between them) become one.  The tiles of all samples are
-// numbered consecutively (their count per sample is only known on the device) and handed out grid-stride.
-// Two waves on 64 x 16 tiles and 9 KB of LDS: in the step's pipeline a workgroup costs the time it holds its LDS (the raster, geom
-// and sampler waves of the other chains wait for it), not what it executes - every KB ~ 1 % of the step, and forms of this kernel
-// that stage more (source windows in LDS, prefetches) are faster alone and slower in the step (profiles/r04_experiments_log.md sections 14, 15).
-constexpr int kFuseW = 64, kFuseH = 16;
-constexpr int kFuseCW = 90, kFuseCH = kFuseH * 4 / 3 + 4;  // 64 * 4/3 + 2 columns (even: texel pairs) and a margin for the +2 of the crop size; kFuseH * 4/3 + 2 rows and the same margin (25 for 16 rows)
-constexpr int kFuseWaves = 2, kFuseThreads = 64 * kFuseWaves;
-constexpr int kFuseRows = kFuseH / kFuseWaves;  // rows of B a wave renders in the Y pass
-constexpr int kFuseMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
-// What one tile costs is not its arithmetic but the small dependent loads around it - which sample holds tile t, that
-// sample's record, the four resize-table entries that bound the tile's piece of C, the table entries of the tile's columns
-// and rows: measured per tile of the round-3 kernel (tools/exp_fuse_stamps.py) 11 us of "which tile is next", 6 + 5.5 us
-// in the two resize passes against 6.7 us for the rotation pass with all its gathers.  So the tile loop is a software
-// pipeline: every such load is ISSUED one pass (or one tile) before its value is needed -
-//   top        S1  sample of the next tile (prefix of the samples' tile counts: LDS), its record requested
-//              B   this tile's column / row table entries requested (used in the X and Y passes)
-//   rotation pass  C(i, j) = crop(rotate(shift(T))) sampled into LDS
-//              S2  next tile's box in B, the four table entries that bound its piece of C requested
-//   X pass         M = X-resize of C, in place
-//   Y pass         B = Y-resize of M -> memory
-//              S3  next tile's piece of C and its "inside" flag from the entries requested in S2
-struct FuseTile {
+// bgprep_stream_kernel: ONE WAVE renders a 64 x kPrepH tile of B = the sample's 2W x 2H texture by walking the tile's rows of
+// C = crop(rotate(shift(T))) once, top to bottom, kPrepG rows at a time:
+//   rotation   the group's texels of C are sampled into kPrepG LDS rows (texel pairs, two rounds of gathers in flight);
+//   X resize   lane = column x of the tile computes M(x, j) from LDS row j into a REGISTER; the last three rows of M stay
+//              (m0, m1, m2);
+//   Y resize   source rows are monotone in y, so every row y of B whose last source row is j is complete as soon as M(., j)
+//              exists: it is computed from the register window and stored.
+// C lives in 5.6 KB of LDS per wave, M never exists outside registers, B goes to memory once; no barrier between waves, one
+// pass over the tile, and a tile may be as tall as one likes (its rows of C are streamed; a taller tile recomputes fewer seam
+// rows: 2 of kPrepH / zoom + 2).  The tiles of all samples are numbered consecutively (their count per sample is only known
+// on the device) and handed out grid-stride to kPrepGrid single-wave workgroups (ofdg_api.hip; a bench batch has fewer tiles
+// than that: one tile per wave).
+// Round 5 replaced the round-4 form with it (two-wave workgroups, a 64 x 16 tile's whole piece of C in 9 KB of LDS through
+// three barrier-separated passes; tools/patches/r05_bgprep_fused_kernel.patch): +3 - 4 % on the headline step in same-box
+// A/Bs (profiles/r05_experiments_log.md section 2), no __syncthreads between waves, no cap on a tile's rows.  What decides its
+// speed is the LENGTH OF A WAVE'S DEPENDENT CHAIN per tile - rounds of gathers, then LDS, then stores, and a gather behind a
+// store waits for that store too (vmcnt counts loads and stores in issue order) - so rows are sampled in groups of 16 (groups
+// of 4 / 8: -6 % / -3 %; 44 rows = 16 KB of LDS: -14 %), the next round's gathers are requested before this round is blended
+// (three rounds in flight: 98 registers, -4 %), and a tile is 32 rows (24: faster alone, slower in the step; 16 / 64: -10 %).
+constexpr int kPrepW = 64;                      // columns of B per tile: lane = column
+constexpr int kPrepH = 32;                      // rows of B per tile (<= 64: lane r holds row r's resize entry)
+constexpr int kPrepG = 16;                      // rows of C sampled per group
+constexpr int kPrepCW = 90;                     // columns of C a tile needs at most: 64 * 4/3 + 2, even (texel pairs), + the margin of the crop size
+constexpr int kPrepMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
+// A tile's placement costs small dependent loads - which sample holds tile t (prefix of the samples' tile counts: LDS),
+// that sample's record, the four resize-table entries that bound the tile's piece of C - so a workgroup that has another
+// tile to do requests those for the NEXT tile (scalar loads) at the top of this tile's turn.
+struct PrepTile {
   int s;                    // sample; n_samples: no tile left
   int bx0, bx1, by0, by1;   // texels of B the tile renders
   int cx0, cx1, cy0, cy1;   // texels of C it needs
   int fits;                 // ... which fit the LDS tile of C
   int inside;               // no mirroring / clamping anywhere in the tile: the per-texel range tests are skipped
 };
-__host__ __device__ __forceinline__ bool fuse_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
-__host__ __device__ __forceinline__ int fuse_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kFuseW) / kFuseW; }
-__host__ __device__ __forceinline__ int fuse_tile_rows(const DevBgPrep& q) { return (q.ry1 - q.ry0 + kFuseH) / kFuseH; }
+__host__ __device__ __forceinline__ bool prep_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
+__host__ __device__ __forceinline__ int prep_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kPrepW) / kPrepW; }
+__host__ __device__ __forceinline__ int prep_tile_rows(const DevBgPrep& q) { return (q.ry1 - q.ry0 + kPrepH) / kPrepH; }
 // cimg_resize_range with the two table entries it reads already in hand (e0 = at[n * s + d0], e1 = at[n * s + d1])
-__device__ __forceinline__ void fuse_range(int n, int s, int d0, int d1, int e0, int e1, int* lo, int* hi) {
+__device__ __forceinline__ void prep_range(int n, int s, int d0, int d1, int e0, int e1, int* lo, int* hi) {
   if (s > n) { *lo = e0; *hi = min(e1 + 1, n - 1); }
   else if (s == n) { *lo = d0; *hi = d1; }
   else { *lo = (d0 * n) / s; *hi = ((d1 + 1) * n - 1) / s; }
 }
 // the tile's piece of C and whether the whole of it maps inside the source image (S3)
-__device__ __forceinline__ void fuse_finish_tile(const DevBgPrep& p, FuseTile& F, int TW, int TH, int ex0, int ex1, int ey0, int ey1) {
-  fuse_range(p.cw, TW, F.bx0, F.bx1, ex0, ex1, &F.cx0, &F.cx1);
-  fuse_range(p.ch, TH, F.by0, F.by1, ey0, ey1, &F.cy0, &F.cy1);
+__device__ __forceinline__ void prep_finish_tile(const DevBgPrep& p, PrepTile& F, int TW, int TH, int ex0, int ex1, int ey0, int ey1) {
+  prep_range(p.cw, TW, F.bx0, F.bx1, ex0, ex1, &F.cx0, &F.cx1);
+  prep_range(p.ch, TH, F.by0, F.by1, ey0, ey1, &F.cy0, &F.cy1);
   const int cx0 = F.cx0, cx1 = F.cx1, cy0 = F.cy0, cy1 = F.cy1;
-  F.fits = (cx1 - cx0 + 1 <= kFuseCW && cy1 - cy0 + 1 <= kFuseCH) ? 1 : 0;
+  F.fits = cx1 - cx0 + 1 <= kPrepCW ? 1 : 0;  // (rows are streamed: any number of them)
   // The usual tile: its crop coordinates need no mirroring and its four corners - so, the map being affine, all its texels
   // (a margin of one texel covers the rounding of the per-texel evaluation) - lie inside the source image: no per-texel tests.
   bool inside = F.fits && bgprep_shift_plain(p) && p.x0 + cx0 >= 0 && p.x0 + cx1 + 1 < p.rw && p.y0 + cy0 >= 0 && p.y0 + cy1 < p.rh;
@@ -2066,7 +2072,7 @@ __device__ __forceinline__ uint32_t enlarge_texel_fix(uint32_t t1, uint32_t t2, 
   }
   return out;
 }
-// Shrinking by less than half (n <= 2 sdim: what a fused tile holds, fuse_sample_fits): destination texel k averages the source
+// Shrinking by less than half (n <= 2 sdim: what a tile of the one-launch form holds, prep_sample_fits): destination texel k averages the source
 // interval [k n, (k + 1) n) in units of 1 / sdim, which touches at most THREE source texels j0, j0 + 1, j0 + 2 with overlap
 // lengths d0 > 0, d1, d2 >= 0 (sum n).  The taps depend on (n, sdim, k) only: once per column of a tile in the X pass, once
 // per row in the Y pass (scalar) - not per texel.
@@ -2092,31 +2098,84 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
   asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// one axis of CImg's linear get_resize with the destination pixel's table entry (a0 = at[k], al = alpha[k]) already in hand
-// (cimg_resize_texel without its two loads); fw: the entry's weight in fixed point, fast: every lane's entry is exact (uniform);
-// st: the taps of a shrinking axis, jmax: the last source index the tile holds (a tap of weight 0 beyond it is read from jmax),
-// mdiv = ceil(2^32 / n), div24: n > 256 (uniform)
-template <class Texel>
-__device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k, int a0, double al, const FixWeight& fw, bool fast, const ShrinkTaps& st,
-                                                          int jmax, uint32_t mdiv, bool div24, Texel texel) {
+// bgprep_rot_inside2 in two halves - the four 8-byte gathers of a texel pair requested, and the pair blended - so that the
+// next pair's gathers can be in flight while this one is blended
+struct RotTaps { uint2 a0, a1, b0, b1; f32x2 dx, dy; int ja, jb; };
+__device__ __forceinline__ RotTaps rot_issue(const DevBgPrep& p, const RotPair& r) {
+  const char* imgc = (const char*)p.image_addr;
+  const uint32_t upw = (uint32_t)p.pw;
+  const f32x2 mx = r.mx, my = r.my;
+  const int x0i = (int)mx.x, y0i = (int)my.x, x1i = (int)mx.y, y1i = (int)my.y;
+  RotTaps t;
+  t.dx = mx - f32x2{(float)x0i, (float)x1i};
+  t.dy = my - f32x2{(float)y0i, (float)y1i};
+  auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
+  auto pair = [&](int row, int col) { return gload2(imgc, (__umul24((uint32_t)row, upw) + (uint32_t)col) * 4u); };
+  t.ja = x0i - p.shx; t.jb = x1i - p.shx;
+  const int basea = t.ja >= 0 ? t.ja : max(-t.ja - 2, 0), baseb = t.jb >= 0 ? t.jb : max(-t.jb - 2, 0);
+  t.a0 = pair(sh(y0i, p.shy), basea); t.a1 = pair(sh(y0i + 1, p.shy), basea);
+  t.b0 = pair(sh(y1i, p.shy), baseb); t.b1 = pair(sh(y1i + 1, p.shy), baseb);
+  return t;
+}
+__device__ __forceinline__ uint2 rot_finish(const RotTaps& t) {
+  const bool reva = t.ja < 0, swapa = t.ja < -1, revb = t.jb < 0, swapb = t.jb < -1;
+  const uint32_t cc0 = swapa ? t.a0.y : t.a0.x, nc0 = reva ? t.a0.x : t.a0.y, cn0 = swapa ? t.a1.y : t.a1.x, nn0 = reva ? t.a1.x : t.a1.y;
+  const uint32_t cc1 = swapb ? t.b0.y : t.b0.x, nc1 = revb ? t.b0.x : t.b0.y, cn1 = swapb ? t.b1.y : t.b1.x, nn1 = revb ? t.b1.x : t.b1.y;
+  return rot_blend2(cc0, nc0, cn0, nn0, cc1, nc1, cn1, nn1, t.dx, t.dy);
+}
+// entry [idx] of a resize table of 16-bit entries, for a uniform idx, as ONE scalar load (the tables are constant while the
+// kernel runs; there is no scalar load of 16 bits: the dword that holds the entry, hipMalloc'ed base)
+__device__ __forceinline__ int tab_entry_uniform(const uint16_t* at, uint32_t idx) {
+  const uint32_t w = ((OFDG_CONSTANT const uint32_t*)at)[idx >> 1];
+  return (int)((w >> ((idx & 1u) * 16u)) & 0xffffu);
+}
+// One destination pixel's share of a resize axis (n source, sdim destination pixels) in three registers - the kernel keeps one
+// per lane for its column and one per lane for "its" row all through a tile, so they are packed:
+//   enlarging   u0 = source index a0, u1 = A1, u2 = A0 | exact << 31   (fix_weight of the table's alpha; not exact: u1 = u2 = 0)
+//   same size   u0 = k
+//   shrinking   u0 = first source index j0, u1 = d0, u2 = d1           (shrink_taps; d2 = n - d0 - d1)
+struct AxisEntry { int u0; uint32_t u1, u2; };
+__device__ __forceinline__ AxisEntry axis_entry(int n, int sdim, int k, const uint16_t* __restrict__ at, const double* __restrict__ alpha) {
+  AxisEntry e{k, 0u, 0u};
   if (sdim > n) {
-    const uint32_t t1 = texel(a0), t2 = a0 < n - 1 ? texel(a0 + 1) : t1;
-    if (fast) return enlarge_texel_fix(t1, t2, fw.a1, fw.a0);
+    const uint32_t i = (uint32_t)(n * sdim + k);
+    e.u0 = at[i];
+    const FixWeight w = fix_weight(alpha[i]);
+    if (w.exact) { e.u1 = (uint32_t)w.a1; e.u2 = (uint32_t)w.a0 | 0x80000000u; }
+  } else if (sdim < n) {
+    const ShrinkTaps t = shrink_taps(n, sdim, k);
+    e.u0 = t.j0; e.u1 = t.d0; e.u2 = t.d1;
+  }
+  return e;
+}
+// the last source index the pixel needs
+__device__ __forceinline__ int axis_last(int n, int sdim, int u0, uint32_t u1, uint32_t u2) {
+  if (sdim > n) return min(u0 + 1, n - 1);
+  if (sdim == n) return u0;
+  return u0 + ((uint32_t)n - u1 - u2 > 0u ? 2 : (u2 > 0u ? 1 : 0));
+}
+// ... and its value from the source texels t0, t1, t2 at u0, u0 + 1, u0 + 2 (clamped by the caller to what exists; enlarging
+// reads t0, t1 - t1 = t0 in the last source pixel -, same size t0).  `exact`: u1 / u2 hold the weight (uniform); otherwise
+// CImg's double form with the table's alpha[k] loaded here (entries at source positions below 128: rare).
+__device__ __forceinline__ uint32_t axis_texel(int n, int sdim, int k, uint32_t u1, uint32_t u2, bool exact, uint32_t t0, uint32_t t1, uint32_t t2,
+                                               uint32_t mdiv, bool div24, const double* __restrict__ alpha) {
+  if (sdim > n) {
+    if (exact) return enlarge_texel_fix(t0, t1, (int)u1, (int)(u2 & 0x7fffffffu));
+    const double al = alpha[(uint32_t)(n * sdim + k)], al1 = 1 - al;
     uint32_t out = 0;
-    const double al1 = 1 - al;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double v1 = u32_to_double((t1 >> (8 * c)) & 255u), v2 = u32_to_double((t2 >> (8 * c)) & 255u);
+      const double v1 = u32_to_double((t0 >> (8 * c)) & 255u), v2 = u32_to_double((t1 >> (8 * c)) & 255u);
       out |= (uint32_t)(unsigned char)(al1 * v1 + al * v2) << (8 * c);
     }
     return out;
   }
-  if (sdim == n) return texel(k);
-  const uint32_t t0 = texel(st.j0), t1 = texel(min(st.j0 + 1, jmax)), t2 = texel(min(st.j0 + 2, jmax));
+  if (sdim == n) return t0;
+  const uint32_t d0 = u1, d1 = u2, d2 = (uint32_t)n - u1 - u2;
   uint32_t acc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
-    acc[c] = __umul24((t2 >> (8 * c)) & 255u, st.d2) + (__umul24((t1 >> (8 * c)) & 255u, st.d1) + __umul24((t0 >> (8 * c)) & 255u, st.d0));
+    acc[c] = __umul24((t2 >> (8 * c)) & 255u, d2) + (__umul24((t1 >> (8 * c)) & 255u, d1) + __umul24((t0 >> (8 * c)) & 255u, d0));
   if (div24) return mulhi_u24(acc[0], mdiv) | (mulhi_u24(acc[1], mdiv) << 8) | (mulhi_u24(acc[2], mdiv) << 16);
   uint32_t out = 0;
 #pragma unroll
@@ -2127,15 +2186,12 @@ __device__ __forceinline__ uint32_t cimg_resize_texel_pre(int n, int sdim, int k
   }
   return out;
 }
-// (six waves per SIMD: at most 80 VGPRs, so that its waves fit beside the compose kernel's)
-__global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
+__global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
                                                            int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
-  __shared__ uint32_t s_c[kFuseCH][kFuseCW];
-  extern __shared__ int s_first[];  // [n_samples + 1]: tiles of the samples before sample i (sized by the launch: LDS the other chains' raster and geom workgroups need is not held for batches that do not exist)
-  const int TW = 2 * W, TH = 2 * H, tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- the tiles of all samples are numbered consecutively: prefix of their counts (wave 0, 64 samples at a time) ----
-  if (wave == 0) {
+  __shared__ uint32_t s_c[kPrepG][kPrepCW];
+  extern __shared__ int s_first[];  // [n_samples + 1]: tiles of the samples before sample i
+  const int TW = 2 * W, TH = 2 * H, lane = threadIdx.x;
+  {  // the tiles of all samples are numbered consecutively: prefix of their counts, 64 samples at a time
     int running = 0;
     if (lane == 0) s_first[0] = 0;
     for (int c = 0; c < n_samples; c += 64) {
@@ -2143,9 +2199,9 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
       int nt = 0;
       if (i < n_samples) {
         const DevBgPrep& q = prep[i];
-        const bool fits = fuse_sample_fits(q, cap_cw, cap_ch);
+        const bool fits = prep_sample_fits(q, cap_cw, cap_ch);
         if (!fits && blockIdx.x == 0) atomicOr(err, kErrBgPrepCapacity);
-        nt = fits ? fuse_tile_cols(q) * fuse_tile_rows(q) : 0;
+        nt = fits ? prep_tile_cols(q) * prep_tile_rows(q) : 0;
       }
       const int incl = wave_scan_incl(nt);
       if (i < n_samples) s_first[i + 1] = running + incl;
@@ -2153,135 +2209,138 @@ __global__ __launch_bounds__(kFuseThreads, 6) void bgprep_fused_kernel(const Dev
     }
   }
   __syncthreads();
-  // (what is read from LDS or through a vector load is a per-lane value to the compiler: readfirstlane says "uniform",
-  //  so that sample records are fetched by scalar loads and tile descriptors live in scalar registers)
   const int total = __builtin_amdgcn_readfirstlane(s_first[n_samples]);
-  auto sample_of = [&](int t, int s) {  // t only grows: s walks the samples once
-    while (s < n_samples && t >= __builtin_amdgcn_readfirstlane(s_first[s + 1])) ++s;
-    return s;
+  // the sample that holds tile t: the number of samples whose tiles end at or before t (64 samples per ballot)
+  auto sample_of = [&](int t) {
+    int n = 0;
+    for (int c = 0; c < n_samples; c += 64) {
+      const int i = c + lane;
+      n += __popcll(__ballot(i < n_samples && t >= s_first[i + 1]));
+    }
+    return __builtin_amdgcn_readfirstlane(n);
   };
-  // resize-table entry [n * dim + k] of a source length n (rows n >= dim do not exist: no table is used for them)
   auto tab_index = [](int n, int dim, int k) { return (uint32_t)(n < dim ? n * dim + k : 0); };
-  // the fields of a sample's record that place a tile in B and pick its rows of the resize tables
   struct PrepBox { int cw, ch, rx0, ry0, rx1, ry1; };
-  typedef OFDG_CONSTANT const DevBgPrep ConstPrep;  // (see below)
+  typedef OFDG_CONSTANT const DevBgPrep ConstPrep;  // (records are constant while this kernel runs: scalar loads)
   auto box_fields = [&](int s) { const ConstPrep& q = ((ConstPrep*)prep)[s]; return PrepBox{q.cw, q.ch, q.rx0, q.ry0, q.rx1, q.ry1}; };
-  auto box_of = [&](const PrepBox& q, int t, int s, FuseTile& F) {  // the tile's texels of B
-    const int tcols = (q.rx1 - q.rx0 + kFuseW) / kFuseW;
+  auto box_of = [&](const PrepBox& q, int t, int s, PrepTile& F) {  // the tile's texels of B
+    const int tcols = (q.rx1 - q.rx0 + kPrepW) / kPrepW;
     const int ti = t - __builtin_amdgcn_readfirstlane(s_first[s]), ty = ti / tcols, tx = ti - ty * tcols;
     F.s = s;
-    F.bx0 = q.rx0 + tx * kFuseW; F.bx1 = min(F.bx0 + kFuseW - 1, q.rx1);
-    F.by0 = q.ry0 + ty * kFuseH; F.by1 = min(F.by0 + kFuseH - 1, q.ry1);
+    F.bx0 = q.rx0 + tx * kPrepW; F.bx1 = min(F.bx0 + kPrepW - 1, q.rx1);
+    F.by0 = q.ry0 + ty * kPrepH; F.by1 = min(F.by0 + kPrepH - 1, q.ry1);
   };
   int t = blockIdx.x;
   if (t >= total) return;
-  FuseTile cur;
+  PrepTile cur;
   int ex0, ex1, ey0, ey1;  // the four table entries that bound the tile's piece of C (requested one tile ahead)
-  {  // the first tile: nothing to overlap its loads with
-    const int s0 = sample_of(t, 0);
+  {
+    const int s0 = sample_of(t);
     const PrepBox q = box_fields(s0);
     box_of(q, t, s0, cur);
-    ex0 = __builtin_amdgcn_readfirstlane((int)T.at_x[tab_index(q.cw, TW, cur.bx0)]); ex1 = __builtin_amdgcn_readfirstlane((int)T.at_x[tab_index(q.cw, TW, cur.bx1)]);
-    ey0 = __builtin_amdgcn_readfirstlane((int)T.at_y[tab_index(q.ch, TH, cur.by0)]); ey1 = __builtin_amdgcn_readfirstlane((int)T.at_y[tab_index(q.ch, TH, cur.by1)]);
+    ex0 = tab_entry_uniform(T.at_x, tab_index(q.cw, TW, cur.bx0)); ex1 = tab_entry_uniform(T.at_x, tab_index(q.cw, TW, cur.bx1));
+    ey0 = tab_entry_uniform(T.at_y, tab_index(q.ch, TH, cur.by0)); ey1 = tab_entry_uniform(T.at_y, tab_index(q.ch, TH, cur.by1));
   }
   for (;;) {
-    // ---- S1: this tile's sample record and the placement fields of the next tile's (scalar loads, one wait for both).
-    // The records are constant while this kernel runs: read through the CONSTANT address space they are fetched by scalar
-    // loads even behind the kernel's own stores, which the compiler must otherwise assume could alias them. ----
+    // ---- this tile's sample record, the placement of the next tile and the entries that bound ITS piece of C: scalar loads,
+    // requested here, used at the top of the next turn ----
     const int tn = t + (int)gridDim.x;
     const bool more = tn < total;
     const int sc = __builtin_amdgcn_readfirstlane(cur.s);
-    const int sn = __builtin_amdgcn_readfirstlane(more ? sample_of(tn, sc) : sc);
+    const int sn = more ? sample_of(tn) : sc;
     const DevBgPrep p = ((ConstPrep*)prep)[sc];
     const PrepBox qn = box_fields(sn);
-    // ---- S3 (of the previous iteration's requests): this tile's piece of C and its "inside" flag ----
-    fuse_finish_tile(p, cur, TW, TH, ex0, ex1, ey0, ey1);
+    prep_finish_tile(p, cur, TW, TH, ex0, ex1, ey0, ey1);
     const int bx0 = cur.bx0, bx1 = cur.bx1, by0 = cur.by0, by1 = cur.by1;
-    const int cx0 = cur.cx0, cx1 = cur.cx1, cy0 = cur.cy0;
-    const int ncw = cx1 - cx0 + 1, nch = cur.cy1 - cy0 + 1;
-    // ---- B: this tile's table entries: column x of the X pass (per lane), the wave's rows of the Y pass (lane r) ----
+    const int cx0 = cur.cx0, cx1 = cur.cx1, cy0 = cur.cy0, cy1 = cur.cy1;
+    const int ncw = cx1 - cx0 + 1, nch = cy1 - cy0 + 1;
+    // this tile's resize entries: column bx0 + lane (the X pass), row by0 + lane (the Y pass: lane r holds row r's)
     const int x = bx0 + lane;
-    const uint32_t ix = tab_index(p.cw, TW, min(x, bx1));
-    const int xa0 = T.at_x[ix];
-    const double xal = T.alpha_x[ix];
-    const uint32_t iy = tab_index(p.ch, TH, min(by0 + wave * kFuseRows + (lane & (kFuseRows - 1)), by1));
-    const int ya0v = T.at_y[iy];
-    const double yalv = T.alpha_y[iy];
-    // ---- S2: the next tile's box, and the four table entries that bound its piece of C (used at the top of its turn) ----
-    FuseTile nxt = cur;
-    int vx0 = 0, vx1 = 0, vy0 = 0, vy1 = 0;
+    const bool have_x = x <= bx1;
+    const AxisEntry ex = axis_entry(p.cw, TW, min(x, bx1), T.at_x, T.alpha_x);
+    const AxisEntry ey = axis_entry(p.ch, TH, min(by0 + lane, by1), T.at_y, T.alpha_y);
+    PrepTile nxt = cur;
+    int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;
     if (more) {
       box_of(qn, tn, sn, nxt);
-      vx0 = T.at_x[tab_index(qn.cw, TW, nxt.bx0)]; vx1 = T.at_x[tab_index(qn.cw, TW, nxt.bx1)];
-      vy0 = T.at_y[tab_index(qn.ch, TH, nxt.by0)]; vy1 = T.at_y[tab_index(qn.ch, TH, nxt.by1)];
+      nx0 = tab_entry_uniform(T.at_x, tab_index(qn.cw, TW, nxt.bx0)); nx1 = tab_entry_uniform(T.at_x, tab_index(qn.cw, TW, nxt.bx1));
+      ny0 = tab_entry_uniform(T.at_y, tab_index(qn.ch, TH, nxt.by0)); ny1 = tab_entry_uniform(T.at_y, tab_index(qn.ch, TH, nxt.by1));
     }
     if (!cur.fits) {  // (a crop beyond 4/3 of the texture: the host launches the two-kernel form for such pools)
-      if (tid == 0) atomicOr(err, kErrBgPrepCapacity);
+      if (lane == 0) atomicOr(err, kErrBgPrepCapacity);
     } else {
-      // ---- rotation pass: C(i, j), texel pairs ----
-      const int pairs = (ncw + 1) / 2;
-      const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48 (pairs <= 45; both factors below 2^24)
-      if (cur.inside) {
-        for (int k = tid; k < pairs * nch; k += kFuseThreads) {
-          const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-          const int pi = k - jj * pairs;
-          const int xi = p.x0 + cx0 + 2 * pi;
-          const RotPair r = bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + jj), p.rh2));
-          *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_inside2(p, r, true);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
-        }
-      } else {
-        for (int k = tid; k < pairs * nch; k += kFuseThreads) {
-          const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-          const int pi = k - jj * pairs;
-          const int i = cx0 + 2 * pi, j = cy0 + jj;
-          const bool second = i + 1 <= cx1;
-          const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
-          const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-          const uint2 v = bgprep_rot_sample2(p, xc0, xc1, yc, second);
-          *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = v;
-        }
-      }
-    }
-    __syncthreads();
-    // (the entries requested in S2 have arrived behind the rotation pass's own loads; taken over into scalar registers here,
-    //  before this tile's stores: vmcnt counts loads and stores in order, a later wait would also wait for the stores)
-    ex0 = __builtin_amdgcn_readfirstlane(vx0); ex1 = __builtin_amdgcn_readfirstlane(vx1);
-    ey0 = __builtin_amdgcn_readfirstlane(vy0); ey1 = __builtin_amdgcn_readfirstlane(vy1);
-    if (cur.fits) {
-      // ---- X pass: M(x, j) over C(., j), in place: wave w takes rows w, w + kFuseWaves, ...; lane = column of the tile ----
-      const FixWeight xw = fix_weight(xal);
-      const bool xfast = __ballot(x <= bx1 && !xw.exact) == 0ull;  // (the wave's columns all have exact weights: uniform)
-      const uint32_t xdiv = 0xFFFFFFFFu / (uint32_t)p.cw + 1u;
-      const bool xdiv24 = shrink_div24(p.cw);
-      const ShrinkTaps xs = shrink_taps(p.cw, TW, min(x, bx1));  // (this column's taps: the same in every row)
-      for (int jj = wave; jj < nch; jj += kFuseWaves) {
-        uint32_t m = 0;
-        if (x <= bx1) m = cimg_resize_texel_pre(p.cw, TW, x, xa0, xal, xw, xfast, xs, cx1, xdiv, xdiv24, [&](int i) { return s_c[jj][i - cx0]; });
-        __builtin_amdgcn_wave_barrier();  // (the row's reads are complete - their values are in use above - before it is overwritten)
-        if (x <= bx1) s_c[jj][lane] = m;
-      }
-    }
-    __syncthreads();
-    if (cur.fits && x <= bx1) {
-      // ---- Y pass: B(x, y) over M(x, .): wave w takes rows kFuseRows w .. of the tile ----
+      const bool x_exact = __ballot(have_x && TW > p.cw && !(ex.u2 >> 31)) == 0ull;  // (the wave's columns all have exact weights: uniform)
+      const uint32_t xdiv = 0xFFFFFFFFu / (uint32_t)p.cw + 1u, ydiv = 0xFFFFFFFFu / (uint32_t)p.ch + 1u;
+      const bool xdiv24 = shrink_div24(p.cw), ydiv24 = shrink_div24(p.ch);
+      // LDS columns of the X pass's three taps (clamped to what the tile holds; a clamped tap has weight 0 or is not read)
+      const int xi0 = ex.u0 - cx0;
+      const int xi1 = (TW > p.cw ? min(ex.u0 + 1, p.cw - 1) : min(ex.u0 + 1, cx1)) - cx0, xi2 = min(ex.u0 + 2, cx1) - cx0;
+      const int ylastv = axis_last(p.ch, TH, ey.u0, ey.u1, ey.u2);
       uint32_t* Bs = B + (size_t)cur.s * TW * TH;
-      const FixWeight ywv = fix_weight(yalv);  // (lane r: row r's weight)
-      const uint32_t ydiv = 0xFFFFFFFFu / (uint32_t)p.ch + 1u;
-      const bool ydiv24 = shrink_div24(p.ch);
-#pragma unroll
-      for (int r = 0; r < kFuseRows; ++r) {
-        const int y = by0 + wave * kFuseRows + r;
-        const int ya0 = __builtin_amdgcn_readlane(ya0v, r);  // (lane r holds row r's entry)
-        const double yal = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yalv), r), __builtin_amdgcn_readlane(__double2loint(yalv), r));
-        FixWeight yw;
-        yw.a1 = __builtin_amdgcn_readlane(ywv.a1, r); yw.a0 = __builtin_amdgcn_readlane(ywv.a0, r);
-        yw.exact = __builtin_amdgcn_readlane((int)ywv.exact, r) != 0;
-        const ShrinkTaps ys = shrink_taps(p.ch, TH, y);  // (uniform: scalar arithmetic)
-        if (y <= by1) Bs[(uint32_t)(y * TW + x)] = cimg_resize_texel_pre(p.ch, TH, y, ya0, yal, yw, yw.exact, ys, cur.cy1, ydiv, ydiv24, [&](int j) { return s_c[j - cy0][lane]; });
+      uint32_t m0 = 0, m1 = 0, m2 = 0;  // M(x, j - 2), M(x, j - 1), M(x, j)
+      int y = by0;                      // the next row of B to emit ...
+      int ylast = __builtin_amdgcn_readlane(ylastv, 0);  // ... and the last row of M it needs
+      const int pairs = (ncw + 1) / 2;
+      const uint32_t inv_pairs = (1u << 20) / (uint32_t)pairs + 1u;  // k / pairs = (k * inv) >> 20, exact for k <= 45 * 48
+      for (int g0 = 0; g0 < nch; g0 += kPrepG) {
+        const int rows = min(kPrepG, nch - g0);
+        const int items = pairs * rows;
+        // ---- rotation: C(cx0 + 2 pi .., cy0 + g0 + jj), texel pairs ----
+        if (cur.inside) {
+          // two rounds in flight: the next round's four gathers are requested before this round's texels are blended
+          auto issue = [&](int k) {
+            const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+            const int pi = k - jj * pairs;
+            const int xi = p.x0 + cx0 + 2 * pi;
+            return rot_issue(p, bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + g0 + jj), p.rh2)));
+          };
+          RotTaps tcur = issue(min(lane, items - 1));
+          for (int k = lane; k < items; k += 64) {
+            const int kn = k + 64;
+            RotTaps tnext = tcur;
+            if (kn < items) tnext = issue(kn);
+            const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+            const int pi = k - jj * pairs;
+            *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = rot_finish(tcur);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
+            tcur = tnext;
+          }
+        } else {
+          for (int k = lane; k < items; k += 64) {
+            const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+            const int pi = k - jj * pairs;
+            const int i = cx0 + 2 * pi, j = cy0 + g0 + jj;
+            const bool second = i + 1 <= cx1;
+            const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
+            const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
+            *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_sample2(p, xc0, xc1, yc, second);
+          }
+        }
+        __syncthreads();  // (one wave: the rows are complete before its lanes read their neighbours' texels)
+        // ---- X resize into the register window, and every row of B that is complete with it ----
+        for (int r = 0; r < rows; ++r) {
+          const int j = cy0 + g0 + r;
+          m0 = m1; m1 = m2;
+          m2 = have_x ? axis_texel(p.cw, TW, x, ex.u1, ex.u2, x_exact, s_c[r][xi0], s_c[r][xi1], s_c[r][xi2], xdiv, xdiv24, T.alpha_x) : 0u;
+          while (y <= by1 && ylast <= j) {
+            const int rr = y - by0;
+            const int v0 = __builtin_amdgcn_readlane(ey.u0, rr);
+            const uint32_t v1 = (uint32_t)__builtin_amdgcn_readlane((int)ey.u1, rr), v2 = (uint32_t)__builtin_amdgcn_readlane((int)ey.u2, rr);
+            // rows v0, v0 + 1, v0 + 2 of M (uniform), clamped to j = the row's last source row: the window holds j - 2 .. j
+            // (enlarging: j is v0 + 1, or v0 in the last row of M; shrinking: v0 + 2, or v0 + 1 where the third tap has no weight)
+            const int dj = j - v0;
+            uint32_t t0 = m2, t1 = m2;
+            if (dj >= 2) { t0 = m0; t1 = m1; } else if (dj == 1) { t0 = m1; }
+            const uint32_t v = axis_texel(p.ch, TH, y, v1, v2, (v2 >> 31) != 0u, t0, t1, m2, ydiv, ydiv24, T.alpha_y);
+            if (have_x) Bs[(uint32_t)(y * TW + x)] = v;
+            ++y;
+            ylast = y <= by1 ? __builtin_amdgcn_readlane(ylastv, y - by0) : 0x7fffffff;
+          }
+        }
+        __syncthreads();  // (the next group overwrites the rows)
       }
     }
     if (!more) break;
-    __syncthreads();  // (the next tile overwrites the rows)
+    ex0 = nx0; ex1 = nx1; ey0 = ny0; ey1 = ny1;
     cur = nxt;
     t = tn;
   }

@@ -850,7 +850,7 @@ static int ensure_tex_table(ofdg_ctx* c) {
   return OFDG_OK;
 }
 // `fusable`: every pool image is at least 2W x 2H, so a crop is at most 4/3 of the texture (beyond that it is refused), which
-// is what the tiles of bgprep_fused_kernel hold; smaller images are resized by any factor (DG:102-106): the two-kernel form
+// is what the tiles of bgprep_stream_kernel hold; smaller images are resized by any factor (DG:102-106): the two-kernel form
 static void bgprep_caps(ofdg_ctx* c, int* cap_cw, int* cap_ch, bool* fusable) {
   if (c->bg_cap_n == c->pool_n && c->bg_cap_cw > 0) { *cap_cw = c->bg_cap_cw; *cap_ch = c->bg_cap_ch; *fusable = c->bg_fusable; return; }  // (per pool, not per step)
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
@@ -1113,7 +1113,7 @@ static int launch_resident(ofdg_ctx* c, ofdg_ctx::Chain& ch, ofdg_ctx::Slot& sl,
 
 // CImg get_resize(.., 3), enlarging branch: source index and weight of every destination pixel (running double sums,
 // boundary 0) for EVERY source length n < s, entry [n * s + x]; once per context and frame size
-constexpr int kBgPrepFusedBlocks = 2048;  // eight two-wave workgroups per CU walk the batch's 64 x 16 tiles (profiles/r04_experiments_log.md section 14)
+constexpr int kPrepGrid = 4096;  // single-wave workgroups of bgprep_stream_kernel: four per SIMD (2048 / 3072 / 8192: -6 % / -2 % / -1 %, profiles/r05_experiments_log.md section 2)
 static int ensure_bgprep_tables(ofdg_ctx* c) {
   const int TW = 2 * c->prm.width, TH = 2 * c->prm.height;
   if (c->bg_tab_w == TW && c->bg_tab_h == TH) return OFDG_OK;
@@ -1169,8 +1169,8 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
     return OFDG_OK;
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
-  if (fusable && n <= kFuseMaxSamples) {
-    hipExtLaunchKernelGGL(bgprep_fused_kernel, dim3(kBgPrepFusedBlocks), dim3(kFuseThreads), (size_t)(n + 1) * sizeof(int), s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
+  if (fusable && n <= kPrepMaxSamples) {
+    hipExtLaunchKernelGGL(bgprep_stream_kernel, dim3(kPrepGrid), dim3(64), (size_t)(n + 1) * sizeof(int), s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
@@ -1848,24 +1848,24 @@ int ofdg_debug_item_count(ofdg_ctx* c) {
   return n;
 }
 
-// How bgprep_fused_kernel walked the last batch: the number of its tiles (only known on the device: a sample's read region
+// How bgprep_stream_kernel walked the last batch: the number of its tiles (only known on the device: a sample's read region
 // depends on its background motion) and of the workgroups that shared them grid-stride - a test that means to compare the
 // SECOND, third ... tile of a workgroup with the oracle asserts tiles > k * workgroups.  0 tiles: the batch took another form
-// of the preparation (background_prep != 1, pool images smaller than 2W x 2H, more samples than the fused form numbers).
+// of the preparation (background_prep != 1, pool images smaller than 2W x 2H, more samples than the one-launch form numbers).
 int ofdg_debug_bgprep_tiles(ofdg_ctx* c, int* tiles, int* workgroups) {
   if (!c || !tiles || !workgroups || !c->last_slot) return OFDG_EINVAL;
   const ofdg_ctx::Slot& sl = *c->last_slot;
-  *tiles = 0; *workgroups = kBgPrepFusedBlocks;
+  *tiles = 0; *workgroups = kPrepGrid;
   int cap_cw, cap_ch;
   bool fusable;
   bgprep_caps(c, &cap_cw, &cap_ch, &fusable);
   const int n = sl.res_samples;
-  if (c->prm.background_prep != 1 || !fusable || n > kFuseMaxSamples || n < 1 || !sl.d_bgprep.p) return OFDG_OK;
+  if (c->prm.background_prep != 1 || !fusable || n > kPrepMaxSamples || n < 1 || !sl.d_bgprep.p) return OFDG_OK;
   HIP_OK(c, hipDeviceSynchronize());
   std::vector<DevBgPrep> rec((size_t)n);
   HIP_OK(c, hipMemcpy(rec.data(), sl.d_bgprep.p, rec.size() * sizeof(DevBgPrep), hipMemcpyDeviceToHost));
   for (const DevBgPrep& q : rec)
-    if (fuse_sample_fits(q, cap_cw, cap_ch)) *tiles += fuse_tile_cols(q) * fuse_tile_rows(q);
+    if (prep_sample_fits(q, cap_cw, cap_ch)) *tiles += prep_tile_cols(q) * prep_tile_rows(q);
   return OFDG_OK;
 }
 

@@ -6,12 +6,14 @@ the headline runs (background_prep = 1, Texture::getRandomizedCrop(2W, 2H, rot, 
 way a bench step renders it (ofdg_forward_counter on the context's own stream) - and the first sample, one from the middle
 and the LAST TWO samples of the batch compared with oracle.render under oracle.detmath(): frames 0 LSB, flow <= 1 ULP.
 
-Why the last samples: the one-launch form of the preparation (bgprep_fused_kernel) hands the batch's tiles to a fixed
-number of workgroups grid-stride, so tile numbers beyond that number are a workgroup's SECOND, third ... tile - the
-software-pipelined part of its loop (the next tile's placement and table entries carried over from the previous turn).
-The tiles of the last samples have the highest numbers; every test asserts through ofdg_debug_bgprep_tiles that the batch
-holds more than three times as many tiles as there are workgroups, so that the property cannot lapse silently when a grid
-constant changes.  (Config 4 is 8 samples of 1024 x 768 per rank: the same tile count as 32 of 512 x 384.)
+The one-launch form of the preparation (bgprep_stream_kernel) hands the batch's tiles (64 x 32 texels of a sample's
+2W x 2H texture) to a fixed number of single-wave workgroups grid-stride.  A bench batch holds fewer tiles than there are
+workgroups (3 400 - 6 100 against 4 096: one tile per wave, two for some in config 3), so the grid-stride part of the
+kernel's loop - a workgroup's SECOND, third ... tile, with the placement and the bounding table entries of the next tile
+requested a turn ahead - is compared with the oracle on a batch made large enough for it
+(test_preparation_tile_loop_beyond_the_grid: config 2's shape with 128 samples), which asserts through
+ofdg_debug_bgprep_tiles that it holds more than three times as many tiles as there are workgroups, so that the property
+cannot lapse silently when a grid constant or the tile size changes.
 """
 import ctypes as C
 
@@ -86,8 +88,7 @@ def assert_tiles_beyond_the_grid(g, k=3):
 @pytest.mark.parametrize("config", [2, 3, 4, 5])
 def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, config):
     """One rank's batch of BASELINE configs 2-5 exactly as `python bench.py --config N` renders its steps (counter sampler,
-    background_prep = 1, the config's pool): first, middle and last two samples at 0 LSB / <= 1 ULP, and the batch is
-    large enough to take every workgroup of the preparation through more than three tiles."""
+    background_prep = 1, the config's pool): first, middle and last two samples at 0 LSB / <= 1 ULP."""
     import bench
     torch = pytest.importorskip("torch")
     cfg = bench.CONFIGS[config]
@@ -98,7 +99,8 @@ def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, co
     g.forward_counter(first, B, *got, ofdg.STREAM_OWN)
     g.synchronize()
     torch.cuda.synchronize()
-    assert_tiles_beyond_the_grid(g)
+    tiles, groups = g.debug_bgprep_tiles()
+    assert tiles > 0                        # (the one-launch form of the preparation rendered this batch)
     tasks, bps, n = g.sample_counter(first, B)
     which = {0, B // 2, B - 2, B - 1}
     if cfg["mode"] == 9:
@@ -108,6 +110,25 @@ def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, co
         assert deformed, "no deforming background in the batch: pick another step"
         which.add(deformed[-1])
     check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, sorted(which), cfg["pool"][0], crops)
+    g.close()
+
+
+def test_preparation_tile_loop_beyond_the_grid(ofdg, oracle):
+    """Config 2's workload with 128 samples in the batch: more than three times as many tiles as the preparation has
+    workgroups, so every workgroup walks its grid-stride loop to a fourth tile (the next tile's sample, placement and bounding
+    table entries requested a turn ahead).  First, middle and last two samples - the highest tile numbers - against the oracle."""
+    import bench
+    torch = pytest.importorskip("torch")
+    cfg = dict(bench.CONFIGS[2], batch=128)
+    B = cfg["batch"]
+    g, prm, _ = bench_generator(ofdg, bench, cfg, sampler=1)
+    got = ofdg.alloc_outputs(B, cfg["H"], cfg["W"])
+    g.forward_counter(5 * B, B, *got, ofdg.STREAM_OWN)
+    g.synchronize()
+    torch.cuda.synchronize()
+    assert_tiles_beyond_the_grid(g)
+    tasks, bps, n = g.sample_counter(5 * B, B)
+    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, [0, B // 2, B - 2, B - 1], cfg["pool"][0])
     g.close()
 
 
@@ -122,7 +143,7 @@ def test_host_sampled_batch_with_background_preparation_matches_oracle(ofdg, ora
     got = ofdg.alloc_outputs(B, H, W)
     g.render(tasks, B, bps, n, *got)
     g.synchronize()
-    assert_tiles_beyond_the_grid(g)
+    assert g.debug_bgprep_tiles()[0] > 0
     pool_n = cfg["pool"][0]
     i0, i1, fl = got
     for sidx in (0, B // 2, B - 2, B - 1):

@@ -701,7 +701,7 @@ def test_background_prep_every_resize_branch(ofdg, oracle, zoom):
 @pytest.mark.parametrize("zoom", [0.8, 1.2])
 def test_background_prep_border_tiles(ofdg, oracle, zoom):
     """A background that moves further than the margin of its 2W x 2H texture: frame 1 reads the texture up to its borders
-    and beyond (reflection), so the whole texture is prepared - every tile of bgprep_fused_kernel, the ones at the borders
+    and beyond (reflection), so the whole texture is prepared - every tile of bgprep_stream_kernel, the ones at the borders
     included, where the crop leaves the rotated image (zoom < 1: mirrored coordinates, per-texel range tests) - and what
     frame 1 shows of them is compared with the oracle, bit for bit."""
     W, H, B = 160, 100, 4
@@ -1128,11 +1128,12 @@ def test_an_error_word_never_speaks_for_another_batch(ofdg, oracle):
 
 
 def test_background_prep_batches_beyond_one_wave_of_samples(ofdg, oracle):
-    """bgprep_fused_kernel numbers the tiles of all samples through a prefix of their tile counts that wave 0 builds 64 samples
-    at a time: a batch of 150 samples (three rounds of the prefix) renders like the oracle, through the host-sampled path
-    (records uploaded with the batch, the preparation behind raster) and through the device sampler.  (At most 1 800 tiles of
-    a 128 x 96 texture: every workgroup takes ONE tile here.  A workgroup's second and later tiles - the grid-stride part of
-    its loop - are compared with the oracle in tests/test_gpu_bench_parity.py, on the batches bench.py times.)"""
+    """bgprep_stream_kernel numbers the tiles of all samples through a prefix of their tile counts, built 64 samples at a time,
+    and finds a tile's sample with one ballot per 64 samples: a batch of 150 samples (three rounds of both) renders like the
+    oracle, through the host-sampled path (records uploaded with the batch, the preparation behind raster) and through the
+    device sampler.  (A few hundred tiles of a 128 x 96 texture: every workgroup takes at most ONE tile here.  A workgroup's
+    second and later tiles - the grid-stride part of its loop - are compared with the oracle in
+    tests/test_gpu_bench_parity.py::test_preparation_tile_loop_beyond_the_grid.)"""
     W, H, B = 64, 48, 150
     p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1, sampler=1, seed=31, num_objects=3)
     g = ofdg.Generator(p)

@@ -176,6 +176,64 @@ def test_aa_byte_table(oracle):
     assert all(aa[c] == c - 1 for c in range(1, 255))
 
 
+def test_matplotlibs_agg_shows_its_gray8_mask_byte_but_it_is_not_the_releases_blender(oracle):
+    """Could the compiled AGG in this image pin the AA mask byte (MovingObjectBase::draw, DataGenerator.cpp:354-362:
+    renderer_scanline_aa_solid of gray8(255) on a cleared pixfmt_gray8)?  matplotlib's Agg backend renders clip paths with
+    exactly that class pair into its alpha mask (RendererAgg::render_clippath: rendererBaseAlphaMask.clear(gray8(0, 0)),
+    rendererAlphaMask.color(gray8(255, 255)), render_scanlines), and the byte IS observable: an opaque rectangle drawn
+    through the clip path onto a transparent canvas leaves alpha = (255 + 255 m) >> 8 = m (pixfmt_amask_adaptor, then
+    fixed_blender_rgba_plain on a = 0).  What it shows, for every one of the 256 coverage values: m == cover.  That is the
+    ROUNDING gray8 arithmetic of the agg-2.4 svn snapshot matplotlib vendors (gray8::multiply / lerp with base_MSB); the
+    reference pins the 2006 agg-2.4 release tarball (cmake/Dependencies.cmake:7-8), whose blender_gray::blend_pix
+    truncates: m = (255 * ((255 (c + 1)) >> 8)) >> 8 = c - 1 for 0 < c < 255 (the oracle's table).  So this
+    library cannot pin that byte; the difference is one LSB of the mask, inside the north star's 1-LSB frame tolerance."""
+    pytest.importorskip("matplotlib")
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import rcParams
+    from matplotlib.backends.backend_agg import RendererAgg
+    from matplotlib.path import Path
+    from matplotlib.transforms import Affine2D, TransformedPath
+    W, H = 128, 96
+    old = rcParams["path.simplify"]
+    rcParams["path.simplify"] = False
+    try:
+        flip = Affine2D().scale(1, -1).translate(0, H)
+        rect = Path([[0, 0], [W, 0], [W, H], [0, H], [0, 0]], [Path.MOVETO] + [Path.LINETO] * 3 + [Path.CLOSEPOLY])
+
+        def render(poly, through_clip):
+            r = RendererAgg(W, H, 72)
+            gc = r.new_gc()
+            gc.set_antialiased(True)
+            gc.set_linewidth(0)
+            gc.set_snap(False)
+            path = Path(np.vstack([poly, poly[:1]]), [Path.MOVETO] + [Path.LINETO] * (len(poly) - 1) + [Path.CLOSEPOLY])
+            if through_clip:
+                gc.set_clip_path(TransformedPath(path, flip))
+                r.draw_path(gc, rect, Affine2D(), rgbFace=(1, 1, 1, 1))
+            else:
+                r.draw_path(gc, path, flip, rgbFace=(1, 1, 1, 1))
+            return np.asarray(r.buffer_rgba())[:, :, 3].copy()
+        rng = np.random.RandomState(1)
+        seen = np.zeros((256, 256), bool)          # [cover, mask byte]
+        for _ in range(40):
+            n = rng.randint(3, 12)
+            phi = np.sort(rng.uniform(0, 2 * np.pi, n))
+            rr = rng.uniform(5, 40, n)
+            poly = np.stack([64 + rr * np.cos(phi), 48 + rr * np.sin(phi)], 1)
+            cover = render(poly, False)
+            assert np.array_equal(cover, oracle.rasterize(poly, W, H))   # (the pinned raw coverage, as in G3)
+            seen[cover.ravel(), render(poly, True).ravel()] = True
+    finally:
+        rcParams["path.simplify"] = old
+    assert seen.any(axis=1).sum() > 250
+    assert (seen.sum(axis=1) <= 1).all()           # a function of the cover ...
+    c = np.nonzero(seen.any(axis=1))[0]
+    assert np.array_equal(seen.argmax(axis=1)[c], c)   # ... and it is the cover itself: the snapshot's rounding blender
+    _, _, aa = oracle.tables()
+    assert (aa[c] != c).sum() >= 250               # the release's truncating blender, which the oracle restates, is one less
+
+
 @pytest.mark.parametrize("prep", [1, 2], ids=["cimg-chain", "one-resampling"])
 def test_background_prep_identity_is_the_centre_crop(oracle, prep):
     """getRandomizedCrop(2W, 2H, angle 0, zoom 1, shift 0) is the centre 2W x 2H crop:

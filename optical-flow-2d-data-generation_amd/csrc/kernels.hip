@@ -1989,7 +1989,7 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // on the device) and handed out grid-stride to kPrepGrid single-wave workgroups (ofdg_api.hip; a bench batch has fewer tiles
 // than that: one tile per wave).
 // Round 5 replaced the round-4 form with it (two-wave workgroups, a 64 x 16 tile's whole piece of C in 9 KB of LDS through
-// three barrier-separated passes; tools/patches/r05_bgprep_fused_kernel.patch): +3 - 4 % on the headline step in same-box
+// three barrier-separated passes; tools/patches/r05_bgprep_experiment_switches.patch): +3 - 4 % on the headline step in same-box
 // A/Bs (profiles/r05_experiments_log.md section 2), no __syncthreads between waves, no cap on a tile's rows.  What decides its
 // speed is the LENGTH OF A WAVE'S DEPENDENT CHAIN per tile - rounds of gathers, then LDS, then stores, and a gather behind a
 // store waits for that store too (vmcnt counts loads and stores in issue order) - so rows are sampled in groups of 16 (groups

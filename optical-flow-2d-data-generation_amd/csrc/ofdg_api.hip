@@ -883,7 +883,7 @@ static int launch_counter_sampler(ofdg_ctx* c, ofdg_ctx::Slot& sl, long long fir
   const int prep = c->prm.background_prep ? 1 : 0;
   CsRealizeDims D{c->prm.width, c->prm.height, c->pool_n, c->pool_w, c->pool_h, sl.res_samples, stride, prep,
                   c->prm.mode == 9 ? c->crop_server.n_crops : 0, c->fg_src.stride, c->fg_src.origin, c->bg_src.stride, c->bg_src.origin,
-                  (unsigned long long)(uintptr_t)c->pool, c->d_tex_table};
+                  (unsigned long long)(uintptr_t)c->pool, c->d_tex_table, c->prm.mode == 9 ? c->d_cs_croptab : nullptr};
   hipLaunchKernelGGL(cs_sample_realize_kernel, dim3(sl.res_samples * kCsGroups), dim3(64), 0, s, c->cs_mode, D, first_index,
                      sl.d_shapes.p, sl.d_objects.p, sl.d_samples.p, err, sl.d_bgprep.p);
   HIP_OK(c, hipGetLastError());

@@ -106,9 +106,10 @@ def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, co
     if cfg["mode"] == 9:
         # a background that is re-sampled through a warp field may be read ANYWHERE: its whole texture must be prepared (the
         # device sampler once kept the rigid read region for it - found by this test); one such sample is always checked
+        # (the device sampler prepares the window grown by the crop's largest displacement: every such sample is checked)
         deformed = [i for i, t in enumerate(tasks) if bps[t.background].do_warpfield_deformation]
-        assert deformed, "no deforming background in the batch: pick another step"
-        which.add(deformed[-1])
+        assert len(deformed) >= 2, "too few deforming backgrounds in the batch: pick another step"
+        which.update(deformed)
     check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, sorted(which), cfg["pool"][0], crops)
     g.close()
 

@@ -72,7 +72,7 @@ NSLOT = 12
 SEED = 20261003
 EXIT_PORT_TAKEN = 98                    # a rank's exit code: the rendezvous port was taken between the launcher's probe and rank 0's bind
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # G wave64 vector instructions/s: 256 CUs x 4 SIMD16 at 2.4 GHz, 4 cycles per wave64 instruction
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2     # G wave64 vector instructions/s: 256 CUs x 4 SIMDs (32 lanes wide) at 2.4 GHz, 2 cycles per wave64 instruction (MI355X_MICROARCH.md; ONE wave sustains one per 4 cycles)
 
 
 def cpu_baseline(ofdg, gen, cfg, budget_s=24.0, host_pool=128, background_prep=0):
@@ -539,7 +539,7 @@ def main():
         if prep_ms is not None:
             # The step's other heavy kernel is bound by neither HBM nor MFMA (the latency of a wave's dependent chain - gathers, LDS, stores - per tile, and
             # what the co-running kernels leave of the memory pipeline); reported: its launch, and its vector instructions against
-            # the chip's issue rate - 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz - as a utilisation.
+            # the chip's issue rate - 256 CUs x 4 SIMDs, one wave64 vector instruction per 2 cycles, 2.4 GHz - as a utilisation.
             # Instruction counts per launch come from the committed PMC pass of this configuration (null without one).
             valu = prep_pmc.get("valu_instructions_per_launch") if prep_pmc else None
             out["background_prep_kernel"] = {

@@ -4,12 +4,14 @@
 #   centre-crop secondary), the driver's form of it (--gpus 1 --steps 20 --warmup 5), the other BASELINE configurations,
 #   rocprofv3 kernel statistics of the default command, and HBM traffic of the dominant kernel from SEPARATE --pmc FETCH_SIZE /
 #   WRITE_SIZE passes (config 2 with background_prep 1 and 0, config 3).
-# Usage (on the GPU box): bash tools/profile_round.sh r04      -> gpurun_out/<tag>/
+# Usage (on the GPU box): bash tools/profile_round.sh r05 [bench|prof|all]      -> gpurun_out/<tag>/
 : ${GRAFT_REPO_ROOT:?}  # (set by gpurun; refuse to run from an unknown place)
 cd "$GRAFT_REPO_ROOT" || exit 1
-tag=${1:-r04}
+tag=${1:-r05}
+part=${2:-all}   # bench: the bench lines; prof: the rocprofv3 passes (each fits one gpurun call); all: both
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
+if [ "$part" != "prof" ]; then
 echo "[bench] default"; timeout -k 10 500 python3 bench.py > $out/bench_line.json 2> $out/bench_stderr.txt
 echo "[bench] driver-like"; timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_line_driver_like_20_steps.json 2>> $out/bench_stderr.txt
 for cfg in 1 3 4 5; do
@@ -17,6 +19,8 @@ for cfg in 1 3 4 5; do
 done
 echo "[bench] centre crops as the headline"; timeout -k 10 300 python3 bench.py --background-prep 0 --no-cpu-baseline --no-secondary > $out/bench_line_config2_centre_crop.json 2>> $out/bench_stderr.txt
 echo "[bench] resident"; timeout -k 10 300 python3 bench.py --sampler resident --no-cpu-baseline --no-secondary > $out/bench_line_config2_resident.json 2>> $out/bench_stderr.txt
+fi
+if [ "$part" != "bench" ]; then
 cd /tmp && export TMPDIR=/tmp
 echo "[rocprofv3] kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary > $out/bench_line_under_rocprof.json 2>/dev/null
@@ -38,7 +42,10 @@ for arm in "2 1" "2 0" "3 1"; do
   python3 tools/pmcstats.py $out/pmc_write_c${cfg}_p$bgp > $out/pmc_write_size_config${cfg}_background_prep_$bgp.txt
 done
 rm -rf $out/trace $out/pmc_fetch_c* $out/pmc_write_c* $out/pmcdir_valu_c*
-tail -n 12 $out/kernel_stats.txt; grep -A3 compose $out/pmc_fetch_size_config2_background_prep_1.txt $out/pmc_write_size_config2_background_prep_1.txt; python3 -c "
+tail -n 12 $out/kernel_stats.txt; grep -A3 compose $out/pmc_fetch_size_config2_background_prep_1.txt $out/pmc_write_size_config2_background_prep_1.txt
+fi
+cd "$GRAFT_REPO_ROOT"
+python3 -c "
 import json,glob
 for f in sorted(glob.glob('$out/bench_line*.json')):
     try: d=json.load(open(f))

@@ -1983,7 +1983,7 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 //              (m0, m1, m2);
 //   Y resize   source rows are monotone in y, so every row y of B whose last source row is j is complete as soon as M(., j)
 //              exists: it is computed from the register window and stored.
-// C lives in 5.6 KB of LDS per wave, M never exists outside registers, B goes to memory once; no barrier between waves, one
+// C lives in 8.4 KB of LDS per wave, M never exists outside registers, B goes to memory once; no barrier between waves, one
 // pass over the tile, and a tile may be as tall as one likes (its rows of C are streamed; a taller tile recomputes fewer seam
 // rows: 2 of kPrepH / zoom + 2).  The tiles of all samples are numbered consecutively (their count per sample is only known
 // on the device) and handed out grid-stride to kPrepGrid single-wave workgroups (ofdg_api.hip; a bench batch has fewer tiles
@@ -1992,12 +1992,13 @@ __global__ __launch_bounds__(256) void bgprep_resize_kernel(const DevBgPrep* __r
 // three barrier-separated passes; tools/patches/r05_bgprep_experiment_switches.patch): +3 - 4 % on the headline step in same-box
 // A/Bs (profiles/r05_experiments_log.md section 2), no __syncthreads between waves, no cap on a tile's rows.  What decides its
 // speed is the LENGTH OF A WAVE'S DEPENDENT CHAIN per tile - rounds of gathers, then LDS, then stores, and a gather behind a
-// store waits for that store too (vmcnt counts loads and stores in issue order) - so rows are sampled in groups of 16 (groups
-// of 4 / 8: -6 % / -3 %; 44 rows = 16 KB of LDS: -14 %), the next round's gathers are requested before this round is blended
-// (three rounds in flight: 98 registers, -4 %), and a tile is 32 rows (24: faster alone, slower in the step; 16 / 64: -10 %).
+// store waits for that store too (vmcnt counts loads and stores in issue order) - so rows are sampled in groups of 24: most
+// tiles are two groups (groups of 4 / 8: -6 % / -3 %; 16 / 20: the same step with compose's launch 10 us longer; 28: -4 %;
+// 44 rows = 16 KB of LDS: -14 %), the next round's gathers are requested before this round is blended (three rounds in
+// flight: 98 registers, -4 %), and a tile is 32 rows (24: faster alone, slower in the step; 16 / 64: -10 %).
 constexpr int kPrepW = 64;                      // columns of B per tile: lane = column
 constexpr int kPrepH = 32;                      // rows of B per tile (<= 64: lane r holds row r's resize entry)
-constexpr int kPrepG = 16;                      // rows of C sampled per group
+constexpr int kPrepG = 24;                      // rows of C sampled per group
 constexpr int kPrepCW = 90;                     // columns of C a tile needs at most: 64 * 4/3 + 2, even (texel pairs), + the margin of the crop size
 constexpr int kPrepMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // A tile's placement costs small dependent loads - which sample holds tile t (prefix of the samples' tile counts: LDS),

@@ -724,6 +724,34 @@ def test_background_prep_border_tiles(ofdg, oracle, zoom):
     assert ulp_diff(got[2], ef).max() == 0
 
 
+@pytest.mark.parametrize("size,pool", [((200, 120), (3, 520, 300)), ((72, 50), (2, 200, 160)), ((256, 200), (2, 640, 512))])
+def test_background_prep_large_rotations_and_odd_frames(ofdg, oracle, size, pool):
+    """Blueprints a caller may hand over, beyond what the sampler draws: texture rotations of tens of "degrees" (the rotated
+    image's canvas grows, the crop reaches its mirrored borders: the per-texel range tests of every tile), zooms across the
+    whole supported range, both shifts - on frames whose sizes are no multiples of the preparation's 64 x 32 tiles (partial
+    tiles on every edge, tiles taller than the texture).  Bit-exact against the oracle."""
+    W, H = size
+    B = 6
+    p = ofdg.default_params(width=W, height=H, mode=5, background_prep=1)
+    g = ofdg.Generator(p)
+    g.pool_synthetic(pool[0], pool[1], pool[2], 9)
+    host_pool = g.pool_download_all()
+    tasks, bps, n = oracle.Sampler(5, W, H).next(B)
+    rots = (25.0, -40.0, 3.0, -1.5, 90.0, 0.0)
+    zooms = (0.77, 1.3, 1.0, 0.9, 1.1, 0.8)
+    for k, t in enumerate(tasks):
+        b = bps[t.background]
+        b.tex_rot, b.tex_scale = rots[k], zooms[k]
+        b.tex_shift_x, b.tex_shift_y = (W if k & 1 else 0), (H if k & 2 else 0)
+    got = render_gpu(ofdg, g, tasks, B, bps, n)
+    q = params_for_oracle(oracle, p)
+    q.background_prep = 1
+    e0, e1, ef = oracle.render(q, tasks, B, bps, n, host_pool)
+    assert np.array_equal(got[0], e0), (got[0] != e0).mean()
+    assert np.array_equal(got[1], e1), (got[1] != e1).mean()
+    assert ulp_diff(got[2], ef).max() == 0
+
+
 @pytest.mark.parametrize("zoom", [0.76, 0.8, 0.99])
 def test_background_prep_wide_frames_average_over_long_crops(ofdg, oracle, zoom):
     """The moving average of a shrinking resize axis divides by the crop's length n with a multiply-high.  The 24-bit

@@ -146,6 +146,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the pass with the other background mode (centre_crop_backgrounds)")
     ap.add_argument("--chains", type=int, default=0, help="ofdg_params.chains (0: the context's own choice; 1: every kernel of a step runs alone, one step after the other)")
     ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1 (what --gpus N > 1 does by itself)")
+    ap.add_argument("--native-startup", action="store_true",
+                    help="take the N > 1 start-up (RCCL communicator, ONE ncclBroadcast of the setup, receivers' context + pool from it, "
+                         "agreement) also with one rank - implied when the rank is a child of this script's launcher; the rank then runs "
+                         "on the context a RECEIVER builds from the broadcast")
     ap.add_argument("--launch-only", action="store_true",
                     help="launcher check: every rank prints its rank environment as one JSON line and exits (no torch, no GPU)")
     return ap.parse_args(argv)
@@ -226,11 +230,17 @@ class Plumbing:
     of the process is the library's own (csrc/comm.cpp).  If the gloo side cannot be used the same calls run on device
     tensors (torch's NCCL = RCCL) instead; `self.how` says which."""
 
-    def __init__(self, world):
+    def __init__(self, world, group=False):
         self.world = world
         self.how = "single process"
-        if world > 1:
+        self.grouped = world > 1 or group
+        if self.grouped:
             import torch.distributed as dist
+            if "MASTER_PORT" not in os.environ:  # (one rank started by hand with --native-startup: its own rendezvous)
+                import socket
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(so.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             try:
                 dist.init_process_group()  # default backends: gloo for CPU tensors, nccl (RCCL) for device tensors, the latter made on first use
@@ -254,40 +264,52 @@ class Plumbing:
         return [float(v) for v in t.tolist()]
 
     def reduce(self, value, op="max"):
-        return value if self.world == 1 else self._reduce([value], op)[0]
+        return value if not self.grouped else self._reduce([value], op)[0]
 
     def barrier(self):
         import torch
-        if self.world > 1:
+        if self.grouped:
             self._reduce([0.0], "max")
         if torch.cuda.is_available():  # (the CPU test of this class has no device)
             torch.cuda.synchronize()
 
     def gather_ints(self, mine):
         import torch
-        if self.world == 1:
+        if not self.grouped:
             return [list(mine)]
         t = torch.tensor(mine, dtype=torch.int64, device=self.device)
         out = [t.clone() for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [[int(v) for v in o.tolist()] for o in out]
 
+    def gather_floats(self, mine):
+        import torch
+        if not self.grouped:
+            return [list(mine)]
+        t = torch.tensor(mine, dtype=torch.float64, device=self.device)
+        out = [t.clone() for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[float(v) for v in o.tolist()] for o in out]
+
     def store(self):
         return self.dist.distributed_c10d._get_default_store()
 
     def close(self):
-        if self.world > 1:
+        if self.grouped:
             self._reduce([0.0], "max")
             self.dist.destroy_process_group()
 
 
-def make_generator(ofdg, cfg, prm, pl, rank, world, local_rank, allow_fallback, background_prep):
+def make_generator(ofdg, cfg, prm, pl, rank, world, local_rank, allow_fallback, background_prep, native=False):
     """The context + texture pool of this rank.  world > 1: the one collective of this path, native - rank 0's seed /
     stream / pool header + texture index table in ONE ncclBroadcast on the library's own RCCL communicator (the unique id
     travels through the launcher's store).  Success or failure is decided by all ranks together: a root that cannot set
     itself up broadcasts a failure status (bcast_abort) instead of leaving the others in the collective, and after the
-    broadcast the ranks agree (ofdg_comm_agree) that every one of them built its context and pool."""
-    if world == 1:
+    broadcast the ranks agree (ofdg_comm_agree) that every one of them built its context and pool.
+    native (--native-startup) with ONE rank: the same path on a one-rank communicator, and the rank then does what a receiver
+    does - context from the broadcast header (params_of), pool from the header + table (pool_from_setup) - and runs on THAT
+    context (the root's own is closed): an 8-GPU run differs from this by the world size only."""
+    if world == 1 and not native:
         gen = ofdg.Generator(prm)
         gen.pool_synthetic(*cfg["pool"], POOL_SEED)
         return gen, prm, "single process", None
@@ -306,7 +328,10 @@ def make_generator(ofdg, cfg, prm, pl, rank, world, local_rank, allow_fallback, 
         setup, table = comm.bcast_setup(gen)
         local = None
         try:  # alone again: the others must not be left in the next collective if this fails
-            if rank != 0:
+            if rank != 0 or world == 1:
+                if world == 1:  # the root as its own receiver: its context goes, the one built from the broadcast stays
+                    gen.close()
+                    gen = None
                 rccl_ranks = comm.nccl_count()
                 prm = comm.params_of(setup)
                 gen = ofdg.Generator(prm)
@@ -317,6 +342,8 @@ def make_generator(ofdg, cfg, prm, pl, rank, world, local_rank, allow_fallback, 
         if local is not None:
             raise local
         startup = "ofdg_comm_bcast_setup: one ncclBroadcast of the setup header + %d-entry texture index table" % setup.n_table
+        if world == 1:
+            startup += "; one rank (--native-startup): the context and pool in use were built from the broadcast, as a receiving rank builds them"
     except Exception as e:  # noqa: BLE001
         err = e
     finally:
@@ -379,7 +406,7 @@ def timed_pass(ofdg, gen, cfg, pl, outs, steps, warmup, rank, world, stream):
     dt = time.perf_counter() - t0
     pl.barrier()
     gen.synchronize(stream)  # raises if a kernel flagged a capacity error
-    return pl.reduce(dt, "max"), step, host_sampler_rate
+    return pl.reduce(dt, "max"), step, host_sampler_rate, dt
 
 
 def main():
@@ -419,15 +446,18 @@ def main():
                                    world_size=world, device=local_rank, sampler=1 if counter else 0, seed=SEED,
                                    background_prep=background_prep, chains=args.chains)
 
-    pl = Plumbing(world)
-    gen, prm, startup, rccl_ranks = make_generator(ofdg, cfg, params(bgp), pl, rank, world, local_rank, args.allow_fallback, bgp)
+    native = args.native_startup or bool(os.environ.get("OFDG_BENCH_LAUNCHED"))
+    pl = Plumbing(world, group=native)
+    gen, prm, startup, rccl_ranks = make_generator(ofdg, cfg, params(bgp), pl, rank, world, local_rank, args.allow_fallback, bgp, native=native)
     if cfg["mode"] == 9:
         gen.warp_generate(2, SEED)  # seeded displacer lists: every rank generates the same fields
     stream = torch.cuda.current_stream().cuda_stream
     NBUF = 2 * gen.num_chains()
     outs = [ofdg.alloc_outputs(BATCH, H, W) for _ in range(NBUF)]
 
-    dt, step, host_sampler_rate = timed_pass(ofdg, gen, cfg, pl, outs, args.steps, args.warmup, rank, world, stream)
+    dt, step, host_sampler_rate, dt_mine = timed_pass(ofdg, gen, cfg, pl, outs, args.steps, args.warmup, rank, world, stream)
+    # every rank's own rate beside the aggregate (which divides by the SLOWEST rank's time): a straggler shows
+    rank_rates = [args.steps * BATCH / t[0] for t in pl.gather_floats([dt_mine])]
 
     # every rank's first global sample index of steps 0 and 1 (the sharding rule the library applies, gathered)
     shards = pl.gather_ints([ofdg.shard_first_index(k, BATCH, world, rank) for k in (0, 1)])
@@ -470,7 +500,7 @@ def main():
         if cfg["mode"] == 9:
             gen2.warp_generate(2, SEED)
         steps2 = min(args.steps, 1000)
-        dt2, _, _ = timed_pass(ofdg, gen2, cfg, pl, outs, steps2, args.warmup, rank, world, stream)
+        dt2, _, _, _ = timed_pass(ofdg, gen2, cfg, pl, outs, steps2, args.warmup, rank, world, stream)
         v2 = steps2 * BATCH * world / dt2
         secondary = {"value": v2, "unit": "samples/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
                      "whole_step_frac": v2 / world * 38 * W * H / 1e9 / HBM_PEAK_GBS, "background_prep": bgp2,
@@ -487,11 +517,12 @@ def main():
         alg_bytes_per_sample = 38 * W * H  # 32 B/px written (8 fp32 planes) + 6 B/px background read
         samples = args.steps * BATCH * world
         value = samples / dt
-        achieved = BATCH * alg_bytes_per_sample / (compose_ms * 1e-3) / 1e9
         kernel = ("compose_deform" if cfg["mode"] == 9 else "compose_rigid") + ("_pow2_kernel" if W & (W - 1) == 0 else "_kernel")
-        # HBM bytes per launch of that kernel from the PMC passes committed for THIS configuration (tools/profile_round.sh:
-        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script); null when no pass of this config is committed
-        traffic, traffic_src, prep_pmc = None, None, None
+        # From the committed profiles of THIS configuration (tools/profile_round.sh -> profiles/traffic.json): HBM-side bytes per
+        # launch of the step's kernels (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script) and the kernel
+        # that holds the largest share of GPU time in the rocprofv3 --kernel-trace --stats run; null when no pass of this
+        # config is committed.
+        traffic, traffic_src, prep_pmc, traffic_step, dominant = None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -499,11 +530,18 @@ def main():
             if ent and ent.get("kernel") == kernel and ent.get("background_prep", 0) == bgp:
                 traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
                 prep_pmc = ent.get("background_prep_kernel")
+                traffic_step = ent.get("whole_step")
+                dominant = ent.get("dominant_kernel_by_gpu_time")
+        ms_per_step = dt / args.steps * 1e3
+        alg_step = BATCH * alg_bytes_per_sample            # one step = one compose launch per rank = the batch's algorithmic bytes
+        step_gbs = value / world * alg_bytes_per_sample / 1e9  # per GPU
+        per_launch = BATCH * alg_bytes_per_sample / (compose_ms * 1e-3) / 1e9
         out = {
             "metric": "training samples/sec (img0+img1+flow, %dx%d)" % (W, H),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 blends / fp64 affines -> f32 planes", "data": "synthetic",
+            "samples_per_s_by_rank": rank_rates,
             "config": {"workload": cfg["name"] + (
                            "; backgrounds prepared per sample like the reference: getRandomizedCrop(2W, 2H, rot, zoom, shift) (background_prep = 1)" if bgp == 1 else
                            "; CENTRE-CROP backgrounds (background_prep = 0: lighter than the reference's per-sample getRandomizedCrop)" if bgp == 0 else
@@ -516,25 +554,34 @@ def main():
                        "sampler": ("counter (Philox, on the device, inside the timed region; every step renders new samples)"
                                    if counter else "ref (host mt19937 streams) inside the timed region" if cfg["sampler"] == "ref" else
                                    "ref (host mt19937 streams) outside the timed region; %d resident batches rotated" % NSLOT)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel, "kernel_ms": compose_ms,
-                         # the same launch with the device to itself (serialised pass after the timed region)
-                         "kernel_ms_alone": alone["compose"],
-                         "frac_alone": BATCH * alg_bytes_per_sample / (alone["compose"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": BATCH * alg_bytes_per_sample,
-                         # the pipeline runs independent in-order chains: compose launches of neighbouring steps overlap each
-                         # other (and the preparation kernels) on the device, so a launch's duration can exceed the step;
-                         # launches in flight on average = kernel_ms / ms_per_step
-                         "launches_in_flight": compose_ms / (dt / args.steps * 1e3),
-                         "whole_step_frac": value / world * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS,
+            # The roofline of the WHOLE STEP: exactly one compose launch moves a step's algorithmic bytes, and the launches of
+            # neighbouring steps overlap each other and the other kernels, so the sustained rate of those bytes is
+            # algorithmic bytes per step / ms_per_step - recomputable from this line alone.  The figures of ONE launch of the
+            # compose kernel (live HIP events on its stream: a span that contains the overlap, so it can exceed ms_per_step) and
+            # of that launch with the device to itself are under `per_launch`.
+            "roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg_step, "ms_per_step": ms_per_step,
+                         "whole_step_frac": step_gbs / HBM_PEAK_GBS,
                          # the two halves of the algorithmic bytes by themselves (32 B/px written, 6 B/px read)
                          "whole_step_write_frac": value / world * 32 * W * H / 1e9 / HBM_PEAK_GBS,
                          "whole_step_read_frac": value / world * 6 * W * H / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved = algorithmic bytes of one launch / its live HIP-event duration (launches overlap); "
-                                 "whole_step_frac = algorithmic bytes per second of the whole pipeline / peak"},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_whole_step": traffic_step, "dominant_kernel_by_gpu_time": dominant,
+                         "kernel": kernel,
+                         "per_launch": {"kernel": kernel, "algorithmic_bytes_per_launch": alg_step,
+                                        "kernel_ms": compose_ms, "achieved": per_launch, "frac": per_launch / HBM_PEAK_GBS,
+                                        # the same launch with the device to itself (serialised pass after the timed region)
+                                        "kernel_ms_alone": alone["compose"],
+                                        "achieved_alone": alg_step / (alone["compose"] * 1e-3) / 1e9,
+                                        "frac_alone": alg_step / (alone["compose"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        # launches in flight on average = kernel_ms / ms_per_step
+                                        "launches_in_flight": compose_ms / ms_per_step,
+                                        "traffic": traffic},
+                         "note": "achieved = algorithmic bytes of a step (38 B/px x W x H x batch) / ms_per_step, per GPU; frac = achieved / peak; "
+                                 "per_launch: the compose launch by live HIP events (overlapped span) and with the device to itself"},
             "kernel_ms": parts, "kernel_ms_alone": alone,
-            "hbm_gbs_whole_step": value / world * alg_bytes_per_sample / 1e9,
+            "hbm_gbs_whole_step": step_gbs,
         }
         if prep_ms is not None:
             # The step's other heavy kernel is bound by neither HBM nor MFMA (the latency of a wave's dependent chain - gathers, LDS, stores - per tile, and

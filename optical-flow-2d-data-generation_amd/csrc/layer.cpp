@@ -9,6 +9,7 @@
 #include <cstring>
 #include <exception>
 #include <fstream>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -209,7 +210,7 @@ bool read_ppm(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w,
 }
 
 // PNG through the system's libpng 1.6, bound at run time (dlopen: the library is part of the image, a build dependency on
-// it is not wanted).  Its "simplified API" (png.h 1.6: png_image_begin_read_from_file / png_image_finish_read /
+// it is not wanted).  Its "simplified API" (png.h 1.6: png_image_begin_read_from_memory / png_image_finish_read /
 // png_image_free over a caller-owned png_image) is a stable C ABI; the struct below restates png_image field by field.
 // 8-bit R, G, B, A come back as stored (alpha is read and dropped: CImg's load keeps it as a fourth channel the
 // reference never looks at, DataGenerator.cpp:128-131); palette, grey and 16-bit files are expanded by libpng.
@@ -219,7 +220,7 @@ struct PngImage {
   char message[64];
 };
 struct PngApi {
-  int (*begin_read_from_file)(PngImage*, const char*) = nullptr;
+  int (*begin_read_from_memory)(PngImage*, const void*, size_t) = nullptr;
   int (*finish_read)(PngImage*, const void* background, void* buffer, int32_t row_stride, void* colormap) = nullptr;
   void (*image_free)(PngImage*) = nullptr;
   bool ok = false;
@@ -227,10 +228,10 @@ struct PngApi {
     void* h = nullptr;
     for (const char* name : {"libpng16.so.16", "libpng16.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) return;
-    begin_read_from_file = (decltype(begin_read_from_file))dlsym(h, "png_image_begin_read_from_file");
+    begin_read_from_memory = (decltype(begin_read_from_memory))dlsym(h, "png_image_begin_read_from_memory");
     finish_read = (decltype(finish_read))dlsym(h, "png_image_finish_read");
     image_free = (decltype(image_free))dlsym(h, "png_image_free");
-    ok = begin_read_from_file && finish_read && image_free;
+    ok = begin_read_from_memory && finish_read && image_free;
   }
 };
 const PngApi& png_api() { static const PngApi api; return api; }
@@ -243,41 +244,31 @@ bool is_png(const std::string& path) {
   static const unsigned char want[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   return f.gcount() == 8 && std::memcmp(sig, want, 8) == 0;
 }
-// libpng's simplified API hands out 8-bit sRGB samples: a 16-bit file is converted from linear light and a gAMA chunk that
-// is not sRGB's is honoured, while the reference's CImg::load (DataGenerator.cpp:128) keeps the raw sample values with no
-// gamma handling.  Such files would give the pool other bytes than the reference's: they are refused, by a walk over the
-// chunks in front of the image data (IHDR bit depth, gAMA), with the way out in the message.
-bool png_samples_are_raw_8bit(const std::string& path, std::string* why) {
+// libpng's simplified API hands out 8-bit sRGB samples: it honours the file's colour-management chunks (a gAMA that is not
+// sRGB's re-encodes every sample), while the reference's CImg::load (DataGenerator.cpp:128) keeps the raw sample values with
+// no gamma handling.  So the file is decoded from MEMORY with those chunks - gAMA, cHRM, sRGB, iCCP: ancillary, each chunk
+// carries its own CRC - left out: libpng then takes 8-bit samples as what they are, and the pool holds the bytes the
+// reference's holds, whatever the file says about its gamma.  16 bits per sample stay refused, with the way out in the
+// message: CImg would hand the reference's `unsigned char` image the truncated 16-bit values, libpng a conversion from linear
+// light - neither is a texture anybody meant.
+bool png_without_colour_chunks(const std::string& path, std::vector<unsigned char>* out, std::string* why) {
   std::ifstream f(path, std::ios::binary);
-  f.seekg(8);
+  std::vector<unsigned char> in((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   auto be32 = [](const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; };
-  for (int guard = 0; guard < 4096; ++guard) {
-    unsigned char head[8];
-    f.read((char*)head, 8);
-    if (f.gcount() != 8) break;
-    const uint32_t len = be32(head);
-    const std::string type((const char*)head + 4, 4);
-    if (type == "IDAT" || type == "IEND") return true;
-    if (type == "IHDR" || type == "gAMA") {
-      unsigned char data[16] = {0};
-      const uint32_t take = len < 16 ? len : 16;
-      f.read((char*)data, take);
-      if ((uint32_t)f.gcount() != take) break;
-      if (type == "IHDR" && take >= 9 && data[8] == 16) {
-        *why = "16-bit PNG: libpng would convert its samples from linear light, the reference keeps raw values; convert the texture to 8 bit (tools/convert_textures.py)";
-        return false;
-      }
-      if (type == "gAMA" && take >= 4) {
-        const double g = be32(data) / 100000.0;  // file gamma; sRGB's is 1 / 2.2
-        if (g < 0.45455 * 0.95 || g > 0.45455 * 1.05) {
-          *why = "PNG with a gAMA chunk of " + std::to_string(g) + ": libpng would re-encode its samples, the reference keeps raw values; strip the chunk or convert the texture (tools/convert_textures.py)";
-          return false;
-        }
-      }
-      f.seekg((std::streamoff)(len - take) + 4, std::ios::cur);
-    } else {
-      f.seekg((std::streamoff)len + 4, std::ios::cur);
+  if (in.size() < 8) { *why = "truncated PNG"; return false; }
+  out->assign(in.begin(), in.begin() + 8);
+  size_t i = 8;
+  while (i + 12 <= in.size()) {
+    const uint32_t len = be32(&in[i]);
+    const std::string type((const char*)&in[i + 4], 4);
+    if ((size_t)len + 12 > in.size() - i) break;
+    if (type == "IHDR" && len >= 9 && in[i + 8 + 8] == 16) {
+      *why = "16-bit PNG: the reference's 8-bit texture would hold its truncated samples; convert the texture to 8 bit (tools/convert_textures.py)";
+      return false;
     }
+    if (type != "gAMA" && type != "cHRM" && type != "sRGB" && type != "iCCP") out->insert(out->end(), in.begin() + i, in.begin() + i + 12 + len);
+    i += 12 + (size_t)len;
+    if (type == "IEND") return true;
   }
   *why = "truncated PNG";
   return false;
@@ -286,11 +277,12 @@ bool png_samples_are_raw_8bit(const std::string& path, std::string* why) {
 bool read_png(const std::string& path, std::vector<uint8_t>* planar_bgr, int* w, int* h, std::string* why) {
   const PngApi& api = png_api();
   if (!api.ok) { *why = "libpng16 is not available on this system"; return false; }
-  if (!png_samples_are_raw_8bit(path, why)) return false;
+  std::vector<unsigned char> file;
+  if (!png_without_colour_chunks(path, &file, why)) return false;
   PngImage img;
   std::memset(&img, 0, sizeof(img));
   img.version = kPngImageVersion;
-  if (!api.begin_read_from_file(&img, path.c_str())) { *why = img.message; return false; }
+  if (!api.begin_read_from_memory(&img, file.data(), file.size())) { *why = img.message; return false; }
   *w = (int)img.width; *h = (int)img.height;
   if (!planar_bgr) { api.image_free(&img); return true; }
   img.format = kPngFormatRgba;
@@ -340,22 +332,33 @@ void load_texture_collection(ofdg_ctx* ctx, const std::string& spec) {
   std::vector<std::vector<uint8_t>> first(1);
   int pw = 0, ph = 0;
   bool mixed = false;
-  for (size_t i = 0; i < paths.size() && !mixed; ++i) {  // headers decide
+  // headers decide; every file that cannot be used is named in ONE error (a collection with a few 16-bit PNGs is fixed in one go)
+  std::string unreadable;
+  int n_unreadable = 0;
+  for (size_t i = 0; i < paths.size(); ++i) {
     int w = 0, h = 0;
     std::string why;
+    bool ok = true;
     if (is_png(paths[i])) {
-      if (!read_png(paths[i], nullptr, &w, &h, &why)) throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + ": " + why + ")");
+      ok = read_png(paths[i], nullptr, &w, &h, &why);
     } else {
       std::ifstream f(paths[i], std::ios::binary);
       std::string magic;
-      if (!f.is_open() || !(f >> magic) || magic != "P6") throw std::runtime_error("Could not open texture collection (cannot read " + paths[i] + ": neither a binary PPM nor a PNG)");
-      for (int k = 0; k < 2; ++k) {
+      if (!f.is_open() || !(f >> magic) || magic != "P6") { ok = false; why = "neither a binary PPM nor a PNG"; }
+      for (int k = 0; ok && k < 2; ++k) {
         for (;;) { const int ch = f.peek(); if (ch == '#') { std::string line; std::getline(f, line); } else if (std::isspace(ch)) f.get(); else break; }
         f >> (k == 0 ? w : h);
       }
     }
-    if (i == 0) { pw = w; ph = h; } else if (w != pw || h != ph) mixed = true;
+    if (!ok) {
+      if (++n_unreadable <= 16) unreadable += (unreadable.empty() ? "" : "; ") + paths[i] + ": " + why;
+      continue;
+    }
+    if (pw == 0 && ph == 0) { pw = w; ph = h; } else if (w != pw || h != ph) mixed = true;
   }
+  if (n_unreadable)
+    throw std::runtime_error("Could not open texture collection (cannot read " + std::string(n_unreadable == 1 ? "" : std::to_string(n_unreadable) + " files: ") + unreadable +
+                             (n_unreadable > 16 ? "; ..." : "") + ")");
   const int rc_alloc = mixed ? ofdg_pool_alloc_mixed(ctx, (int)paths.size()) : ofdg_pool_alloc(ctx, (int)paths.size(), pw, ph);
   if (rc_alloc != OFDG_OK) throw std::runtime_error(std::string("Could not open texture collection: ") + ofdg_last_error(ctx));
   for (size_t i = 0; i < paths.size(); ++i) {
@@ -506,20 +509,25 @@ void DataGenerationLayer::Forward_gpu(const std::vector<Blob*>& bottom, const st
     if (hipEventSynchronize((hipEvent_t)ring_done_[(size_t)(consumed_ % P)]) != hipSuccess)
       throw std::runtime_error("DataGenerationLayer::Forward: hipEventSynchronize failed");
     // THIS batch's device error flags (a flag raised by a younger batch still rendering is reported at that batch's own turn).
-    // The word is cleared by the read, so the error is reported once: a truncated batch is RETIRED before the exception
-    // leaves - its buffer set goes back to the ring and its successor starts rendering - so that a caller that catches the
-    // exception and calls Forward again gets the NEXT batch, never the bad one as a valid top (the reference drops a bad
-    // sample and leaves stale data in its batch slot, DG:1285-1292).
+    // The word is cleared by the read, so the error is reported once.  A truncated batch is RETIRED like a good one before
+    // the exception leaves: the tops point at ITS buffer set - the one set no batch in flight renders into until the next
+    // Forward, so what a caller that catches the exception still reads there is stable (and marked bad by the exception:
+    // the reference drops a bad sample and leaves stale data in its batch slot, DG:1285-1292) - and its successor starts
+    // rendering; the next Forward hands out the NEXT batch.
     std::string bad;
     if (ofdg_poll_errors_of(ctx_, ring_ticket_[(size_t)(consumed_ % P)]) != OFDG_OK) bad = ofdg_last_error(ctx_);
     float** set = &ring_[(size_t)(consumed_ % P) * 3];
-    if (bad.empty())
-      for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
+    for (int k = 0; k < 3; ++k) top[k]->set_gpu_data(set[k]);
     ++consumed_;
     in_flight_ = 0;
     for (long long b = consumed_; b < produced_; ++b)
       if (hipEventQuery((hipEvent_t)ring_done_[(size_t)(b % P)]) == hipErrorNotReady) ++in_flight_;
-    while (produced_ < consumed_ + P - 1) enqueue_next();
+    try {
+      while (produced_ < consumed_ + P - 1) enqueue_next();
+    } catch (const std::exception& e) {  // (the batch's own error comes first: a failed enqueue shows again at the next Forward)
+      if (bad.empty()) throw;
+      bad += std::string(" (and the next batch could not be enqueued: ") + e.what() + ")";
+    }
     if (!bad.empty()) throw std::runtime_error("DataGenerationLayer::Forward: " + bad);
     return;
   }

@@ -73,6 +73,9 @@ class DataGenerationLayer {
   // blobs at the finished set instead of copying it (valid until the next Forward).
   // Forward waits for the OLDEST set's own completion event only (prefetch_full_.pop,
   // data_generation_layer.cpp:269): the younger batches stay in flight behind it.
+  // A batch a kernel truncated (a device capacity flag of its own ticket) makes Forward throw AFTER the batch is retired:
+  // the tops then point at that batch's buffer set - stable until the next Forward, its contents incomplete - and the
+  // next Forward hands out the next batch.
   void Forward_cpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Forward_gpu(const std::vector<Blob*>& bottom, const std::vector<Blob*>& top);
   void Backward_cpu(const std::vector<Blob*>&, const std::vector<bool>&, const std::vector<Blob*>&) {}

@@ -31,12 +31,30 @@ def check_contract(d):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 6 * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 6e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "per_launch", "algorithmic_bytes_per_step", "ms_per_step",
+                "traffic_whole_step", "dominant_kernel_by_gpu_time"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert r["algorithmic_bytes_per_launch"] == 38 * 512 * 384 * d["config"]["batch_per_gpu"]
+    # every fraction of the block can be recomputed from the line alone: the whole step's first ...
+    assert r["algorithmic_bytes_per_step"] == 38 * 512 * 384 * d["config"]["batch_per_gpu"] and r["ms_per_step"] == d["ms_per_step"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac"] == r["whole_step_frac"]
+    assert abs(r["achieved"] - d["value"] / d["n_gpus"] * 38 * 512 * 384 / 1e9) < 1e-9 * r["achieved"]
+    # ... then one launch of the compose kernel: live HIP events in the pipeline (an overlapped span) and with the device to itself
+    q = r["per_launch"]
+    assert q["kernel"] == r["kernel"] and q["algorithmic_bytes_per_launch"] == r["algorithmic_bytes_per_step"]
+    assert abs(q["achieved"] - q["algorithmic_bytes_per_launch"] / (q["kernel_ms"] * 1e-3) / 1e9) < 1e-9 * q["achieved"]
+    assert abs(q["frac"] - q["achieved"] / r["peak"]) < 1e-12
+    assert abs(q["frac_alone"] - q["algorithmic_bytes_per_launch"] / (q["kernel_ms_alone"] * 1e-3) / 1e9 / r["peak"]) < 1e-12
+    assert abs(q["launches_in_flight"] - q["kernel_ms"] / d["ms_per_step"]) < 1e-9
+    if r["traffic_whole_step"]:  # (PMC passes of this configuration are committed: the step's bytes at the L2s' memory side, by kernel)
+        t = r["traffic_whole_step"]
+        assert t["hbm_bytes_per_step"] == sum(t["by_kernel"].values()) and t["by_kernel"][r["kernel"]] == r["traffic"]
+    if r["dominant_kernel_by_gpu_time"]:
+        k = r["dominant_kernel_by_gpu_time"]
+        assert k["kernel"] in k["all"] and abs(sum(v["share"] for v in k["all"].values()) - 1.0) < 1e-6
+    # every rank's own rate beside the aggregate
+    assert len(d["samples_per_s_by_rank"]) == d["n_gpus"] and abs(sum(d["samples_per_s_by_rank"]) - d["value"]) < 1e-6 * d["value"]
     # the context proves how it was set up: chains, hardware queues, shard indices of rank 0
     assert d["config"]["chains"] >= 3 and d["config"]["shards"]["first_index_of_steps_0_and_1_by_rank"] == [[0, d["config"]["batch_per_gpu"]]]
 
@@ -67,6 +85,33 @@ def test_bench_line_through_the_launcher_path_has_the_same_contract():
     check_contract(d)
     assert d["config"]["launched_by"] == "bench.py launcher" and d["config"]["background_prep"] == 1
     assert d["centre_crop_backgrounds"] is None
+    check_native_startup(d)
+
+
+def check_native_startup(d):
+    """The rank took bench.py's N > 1 start-up on a one-rank RCCL communicator (Comm.from_store, bcast_setup, params_of,
+    pool_from_setup, agree, nccl_count) and ran on the context a receiving rank builds from the broadcast."""
+    c = d["config"]
+    assert c["rccl_ranks"] == 1, c
+    assert c["startup"].startswith("ofdg_comm_bcast_setup: one ncclBroadcast") and "built from the broadcast" in c["startup"], c["startup"]
+    assert "gloo" in c["plumbing"]
+    assert c["shards"]["first_index_of_steps_0_and_1_by_rank"] == [[0, c["batch_per_gpu"]]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_native_startup_with_one_rank(config):
+    """`--native-startup`: bench.py's own multi-rank branch at world = 1, for the two configurations BASELINE quotes on 8 GPUs, at
+    their per-GPU batch (config 4: 8 samples of 1024 x 768; config 5: 32 samples on the 10 000 x 1 MP pool) - the 8-GPU run
+    differs from this by the world size only (data_generation_layer.hpp:54 has no counterpart: the reference does not shard)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-secondary", "--native-startup", "--config", str(config)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    check_native_startup(d)
+    assert d["config"]["baseline_config"] == config and d["config"]["batch_per_gpu"] == (8 if config == 4 else 32)
+    assert d["config"]["launched_by"] == "direct" and d["value"] > 0 and len(d["samples_per_s_by_rank"]) == 1
 
 
 @pytest.mark.gpu

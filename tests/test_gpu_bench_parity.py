@@ -3,8 +3,10 @@
 The workloads are bench.CONFIGS themselves (imported: no second copy of the numbers), with the background preparation
 the headline runs (background_prep = 1, Texture::getRandomizedCrop(2W, 2H, rot, zoom, shift), DataGenerator.cpp:87-109,
 1186-1192), the pool bench.py builds (same size, same seed), the seed bench.py uses, one rank's whole batch rendered the
-way a bench step renders it (ofdg_forward_counter on the context's own stream) - and the first sample, one from the middle
-and the LAST TWO samples of the batch compared with oracle.render under oracle.detmath(): frames 0 LSB, flow <= 1 ULP.
+way a bench step renders it (ofdg_forward_counter on the context's own stream) - and EVERY sample of the batch, for two
+different steps per config, compared with oracle.render under oracle.detmath(): frames 0 LSB, flow <= 1 ULP.  The oracle
+renders the samples on the host's threads (one sample per thread, the reference's first_level_threads, DG:1023-1027);
+OFDG_PARITY_SUBSET=1 in the environment falls back to the first, the middle and the last two samples (a box with few cores).
 
 The one-launch form of the preparation (bgprep_stream_kernel) hands the batch's tiles (64 x 32 texels of a sample's
 2W x 2H texture) to a fixed number of single-wave workgroups grid-stride.  A bench batch holds fewer tiles than there are
@@ -40,30 +42,51 @@ def blueprints_of(task, bps):
     return used
 
 
-def check_samples(ofdg, oracle, g, prm, tasks, bps, n_bps, got, which, pool_n, crops=None):
-    """Samples `which` of a rendered batch against the oracle.  The oracle gets a host pool of just the images those samples
-    use (texture ids re-indexed: tex_id % len(images) picks the same image in the small pool)."""
+def check_samples(ofdg, oracle, g, prm, tasks, bps, n_bps, got, which, pool_n, crops=None, detmath=True, flow_ulp=1):
+    """Samples `which` of a rendered batch against the oracle, one oracle call per sample, the calls spread over the host's
+    threads (ctypes releases the GIL; the oracle's mode switches are process-wide and set once around all of them).  Each
+    call gets a host pool of just the images its sample uses (texture ids re-indexed: tex_id % len(images) picks the same
+    image in the small pool)."""
+    import concurrent.futures as cf
     W, H = prm.width, prm.height
-    i0, i1, fl = got
-    for sidx in which:
+    which = list(which)
+    i0, i1, fl = (a.cpu().numpy() for a in got)   # one copy of the whole batch
+
+    def one(sidx, images, host_pool):
         t = tasks[sidx]
-        used = blueprints_of(t, bps)
-        images = sorted({bps[i].tex_id % pool_n for i in used})
-        host_pool = np.stack([g.pool_download(i) for i in images])
         sub = (type(bps[0]) * n_bps)()
         C.memmove(sub, bps, C.sizeof(sub))
-        for i in used:
+        for i in blueprints_of(t, bps):
             sub[i].tex_id = images.index(bps[i].tex_id % pool_n)
         q = oracle.default_params(W, H, prm.mode, prm.use_antialiasing, 1, prm.num_objects)
         q.background_prep = prm.background_prep
-        with oracle.detmath():  # the device sampler builds its affines and the preparation record with include/ofdg_detmath.h
-            e0, e1, ef = oracle.render(q, (type(t) * 1)(t), 1, sub, n_bps, host_pool, warp_crops=crops, reuse=-1)
-        a0, a1, af = i0[sidx].cpu().numpy(), i1[sidx].cpu().numpy(), fl[sidx].cpu().numpy()
+        e0, e1, ef = oracle.render(q, (type(t) * 1)(t), 1, sub, n_bps, host_pool, warp_crops=crops, reuse=-1)
+        a0, a1, af = i0[sidx], i1[sidx], fl[sidx]
         assert np.array_equal(a0, e0[0]), "sample %d image0: %d values differ, max %g" % (sidx, (a0 != e0[0]).sum(), np.abs(a0 - e0[0]).max())
         assert np.array_equal(a1, e1[0]), "sample %d image1: %d values differ, max %g" % (sidx, (a1 != e1[0]).sum(), np.abs(a1 - e1[0]).max())
         assert np.array_equal(np.isnan(af), np.isnan(ef[0]))
         ok = ~np.isnan(ef[0])
-        assert ulp_diff(af[ok], ef[0][ok]).max() <= 1, "sample %d flow" % sidx
+        assert ulp_diff(af[ok], ef[0][ok]).max() <= flow_ulp, "sample %d flow" % sidx
+        return sidx
+
+    import contextlib, os
+    workers = max(1, min(len(which), os.cpu_count() or 1))
+    mode = oracle.detmath() if detmath else contextlib.nullcontext()  # the device sampler builds its affines and the preparation record with include/ofdg_detmath.h
+    with mode, cf.ThreadPoolExecutor(workers) as ex:
+        chunk = 8   # (the pool images of a chunk's samples are downloaded on this thread: the GPU calls stay on one thread)
+        for c in range(0, len(which), chunk):
+            futs = []
+            for sidx in which[c:c + chunk]:
+                images = sorted({bps[i].tex_id % pool_n for i in blueprints_of(tasks[sidx], bps)})
+                futs.append(ex.submit(one, sidx, images, np.stack([g.pool_download(i) for i in images])))
+            for f in futs:
+                f.result()
+    return len(which)
+
+
+def subset_only():
+    import os
+    return os.environ.get("OFDG_PARITY_SUBSET", "0") not in ("", "0")
 
 
 def bench_generator(ofdg, bench, cfg, sampler):
@@ -85,32 +108,38 @@ def assert_tiles_beyond_the_grid(g, k=3):
     return tiles, groups
 
 
+@pytest.mark.parametrize("step", [2, 7])
 @pytest.mark.parametrize("config", [2, 3, 4, 5])
-def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, config):
+def test_bench_batch_with_background_preparation_matches_oracle(ofdg, oracle, config, step):
     """One rank's batch of BASELINE configs 2-5 exactly as `python bench.py --config N` renders its steps (counter sampler,
-    background_prep = 1, the config's pool): first, middle and last two samples at 0 LSB / <= 1 ULP."""
+    background_prep = 1, the config's pool), steps 2 and 7 of rank 0: EVERY sample at 0 LSB / <= 1 ULP (Process_TaskBucket,
+    DG:1175-1254)."""
     import bench
+    import time
     torch = pytest.importorskip("torch")
     cfg = bench.CONFIGS[config]
     B = cfg["batch"]
     g, prm, crops = bench_generator(ofdg, bench, cfg, sampler=1)
     got = ofdg.alloc_outputs(B, cfg["H"], cfg["W"])
-    first = 2 * B   # (step 2 of rank 0: any step is a pure function of (seed, index))
+    first = step * B   # (any step is a pure function of (seed, index))
     g.forward_counter(first, B, *got, ofdg.STREAM_OWN)
     g.synchronize()
     torch.cuda.synchronize()
     tiles, groups = g.debug_bgprep_tiles()
     assert tiles > 0                        # (the one-launch form of the preparation rendered this batch)
     tasks, bps, n = g.sample_counter(first, B)
-    which = {0, B // 2, B - 2, B - 1}
-    if cfg["mode"] == 9:
-        # a background that is re-sampled through a warp field may be read ANYWHERE: its whole texture must be prepared (the
-        # device sampler once kept the rigid read region for it - found by this test); one such sample is always checked
-        # (the device sampler prepares the window grown by the crop's largest displacement: every such sample is checked)
-        deformed = [i for i, t in enumerate(tasks) if bps[t.background].do_warpfield_deformation]
-        assert len(deformed) >= 2, "too few deforming backgrounds in the batch: pick another step"
-        which.update(deformed)
-    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, sorted(which), cfg["pool"][0], crops)
+    which = set(range(B))
+    if subset_only():
+        which = {0, B // 2, B - 2, B - 1}
+        if cfg["mode"] == 9:
+            # a background that is re-sampled through a warp field reads frame 1 at displaced positions (the device sampler once
+            # kept the rigid read region for it - found by this test): every such sample stays in the subset
+            which.update(i for i, t in enumerate(tasks) if bps[t.background].do_warpfield_deformation)
+    if cfg["mode"] == 9 and step == 2:
+        assert sum(1 for t in tasks if bps[t.background].do_warpfield_deformation) >= 2, "too few deforming backgrounds in the batch: pick another step"
+    t0 = time.time()
+    n_checked = check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, sorted(which), cfg["pool"][0], crops)
+    print("config %d step %d: %d of %d samples against the oracle in %.1f s" % (config, step, n_checked, B, time.time() - t0))
     g.close()
 
 
@@ -129,7 +158,8 @@ def test_preparation_tile_loop_beyond_the_grid(ofdg, oracle):
     torch.cuda.synchronize()
     assert_tiles_beyond_the_grid(g)
     tasks, bps, n = g.sample_counter(5 * B, B)
-    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, [0, B // 2, B - 2, B - 1], cfg["pool"][0])
+    which = [0, B // 2, B - 2, B - 1] if subset_only() else range(B)
+    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, which, cfg["pool"][0])
     g.close()
 
 
@@ -145,21 +175,6 @@ def test_host_sampled_batch_with_background_preparation_matches_oracle(ofdg, ora
     g.render(tasks, B, bps, n, *got)
     g.synchronize()
     assert g.debug_bgprep_tiles()[0] > 0
-    pool_n = cfg["pool"][0]
-    i0, i1, fl = got
-    for sidx in (0, B // 2, B - 2, B - 1):
-        t = tasks[sidx]
-        used = blueprints_of(t, bps)
-        images = sorted({bps[i].tex_id % pool_n for i in used})
-        host_pool = np.stack([g.pool_download(i) for i in images])
-        sub = (type(bps[0]) * n)()
-        C.memmove(sub, bps, C.sizeof(sub))
-        for i in used:
-            sub[i].tex_id = images.index(bps[i].tex_id % pool_n)
-        q = oracle.default_params(W, H, cfg["mode"], 1, 1, cfg["nobj"])
-        q.background_prep = 1
-        e0, e1, ef = oracle.render(q, (type(t) * 1)(t), 1, sub, n, host_pool)  # (libm arithmetic: the host path's own)
-        assert np.array_equal(i0[sidx].cpu().numpy(), e0[0]), "sample %d image0" % sidx
-        assert np.array_equal(i1[sidx].cpu().numpy(), e1[0]), "sample %d image1" % sidx
-        assert ulp_diff(fl[sidx].cpu().numpy(), ef[0]).max() == 0, "sample %d flow" % sidx
+    which = [0, B // 2, B - 2, B - 1] if subset_only() else range(B)
+    check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, which, cfg["pool"][0], detmath=False, flow_ulp=0)  # (libm arithmetic: the host path's own)
     g.close()

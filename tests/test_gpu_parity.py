@@ -941,6 +941,38 @@ def test_layer_loads_a_texture_list_with_images_of_different_sizes(ofdg, tmp_pat
     layer.close()
 
 
+def test_layer_names_every_unreadable_texture_in_one_error(ofdg, tmp_path):
+    """A texture list with files the loader cannot use (two 16-bit PNGs, one file that is no image) fails ONCE, naming all of
+    them ("Could not open texture collection", DG:121); a PNG that claims another gamma is not among them - its stored bytes
+    are what the reference's CImg::load keeps (DG:128), and what the pool gets."""
+    import struct
+    from PIL import Image, PngImagePlugin
+    rng = np.random.RandomState(5)
+    rgb = rng.randint(0, 256, (192, 256, 3)).astype(np.uint8)
+    good = tmp_path / "good.png"
+    info = PngImagePlugin.PngInfo()
+    info.add(b"gAMA", struct.pack(">I", 100000))
+    Image.fromarray(rgb).save(good, pnginfo=info)
+    deep = []
+    for k in range(2):
+        p = tmp_path / ("deep%d.png" % k)
+        Image.fromarray((rng.randint(0, 256, (192, 256)).astype(np.uint16) * 257)).save(p)
+        deep.append(p)
+    junk = tmp_path / "junk.ppm"
+    junk.write_bytes(b"not an image")
+    lst = tmp_path / "database.txt"
+    lst.write_text("\n".join(str(p) for p in (good, deep[0], junk, deep[1])) + "\n")
+    with pytest.raises(ofdg.OfdgError) as e:
+        ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
+    msg = str(e.value)
+    assert "Could not open texture collection" in msg and "3 files" in msg
+    assert all(str(p) in msg for p in deep + [junk]) and str(good) not in msg and msg.count("16-bit") == 2
+    lst.write_text(str(good) + "\n")
+    layer = ofdg.DataGenerationLayer(LAYER_PROTOTXT % lst)
+    assert np.array_equal(ofdg.decode_image(good), np.stack([rgb[:, :, 2], rgb[:, :, 1], rgb[:, :, 0]]))
+    layer.close()
+
+
 def test_pool_from_list_decodes_images_like_the_ppm_loader(ofdg, tmp_path):
     """Generator.pool_from_list (Pillow decode of any image format; the reference uses CImg::load) and
     tools/convert_textures.py + the layer's PPM loader fill the pool with the same texels, in B, G, R order;

@@ -467,24 +467,23 @@ def test_native_image_decode_png_and_ppm(ofdg, tmp_path):
     with pytest.raises(ofdg.OfdgError) as e:
         ofdg.decode_image(p)
     assert e.value.code == ofdg.ETEXTURES
-    # PNGs whose samples libpng's 8-bit sRGB output would NOT hand over as stored (the reference's CImg::load keeps raw values,
-    # DataGenerator.cpp:128): a gAMA chunk that is not sRGB's, 16 bits per sample - refused, with the way out in the message;
-    # sRGB's own gamma (what most writers put there) changes nothing and decodes
+    # A PNG's colour-management chunks (gAMA, cHRM, sRGB, iCCP) would make libpng's 8-bit sRGB output re-encode the samples; the
+    # reference's CImg::load keeps raw values (DataGenerator.cpp:128): the loader decodes from memory without those chunks, so
+    # the stored bytes come out whatever gamma the file claims.  16 bits per sample are refused, with the way out in the message.
     import struct
     from PIL import PngImagePlugin
 
-    def with_gamma(g):
+    def with_chunks(gamma=None, srgb=False):
         info = PngImagePlugin.PngInfo()
-        info.add(b"gAMA", struct.pack(">I", int(round(g * 100000))))
+        if srgb:
+            info.add(b"sRGB", b"\x00")
+        if gamma is not None:
+            info.add(b"gAMA", struct.pack(">I", int(round(gamma * 100000))))
         return info
-    p = tmp_path / "h.png"
-    Image.fromarray(rgb).save(p, pnginfo=with_gamma(1.0))
-    with pytest.raises(ofdg.OfdgError) as e:
-        ofdg.decode_image(p)
-    assert e.value.code == ofdg.ETEXTURES and "gAMA" in str(e.value) and "convert_textures" in str(e.value)
-    p = tmp_path / "i.png"
-    Image.fromarray(rgb).save(p, pnginfo=with_gamma(0.45455))
-    assert np.array_equal(ofdg.decode_image(p), want)
+    for name, info in (("h", with_chunks(1.0)), ("i", with_chunks(0.45455)), ("i2", with_chunks(0.0)), ("i3", with_chunks(0.3, srgb=True)), ("i4", with_chunks(srgb=True))):
+        p = tmp_path / (name + ".png")
+        Image.fromarray(rgb).save(p, pnginfo=info)
+        assert np.array_equal(ofdg.decode_image(p), want), name
     p = tmp_path / "j.png"
     Image.fromarray((grey.astype(np.uint16) * 257)).save(p)                # mode I;16
     with pytest.raises(ofdg.OfdgError) as e:

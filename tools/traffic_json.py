@@ -12,6 +12,33 @@ WORK = {2: "mode 5, 512x384, batch 32, 16 objects", 3: "mode 9, 512x384, batch 3
         5: "mode 7, 512x384, batch 32, 10000 x 1 MP pool"}
 
 
+STEP_KERNELS = ("cs_sample_realize", "geom_kernel", "raster_kernel", "bgprep", "compose")
+
+
+def all_kernels(f, counter):
+    """{kernel: counter value} of every kernel of a step in a pmcstats.py summary"""
+    name, out = None, {}
+    for line in open(f):
+        if not line.startswith(" "):
+            name = line.split()[0].replace("ofdg::", "")
+        elif name and any(k in name for k in STEP_KERNELS) and line.split()[0] == counter:
+            out[name] = float(line.split()[1])
+    return out
+
+
+def dominant_kernel(stats_csv):
+    """the kernel with the largest share of GPU time in a rocprofv3 --kernel-trace --stats run (kernel_stats.csv), one-off kernels excluded"""
+    import csv
+    rows = [r for r in csv.DictReader(open(stats_csv)) if r["Name"].startswith("ofdg::") and int(r["Calls"]) > 10]
+    if not rows:
+        return None
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    return {"kernel": r["Name"].split("(")[0].replace("ofdg::", ""), "share_of_the_steps_kernels": float(r["TotalDurationNs"]) / tot,
+            "average_us_per_launch_in_the_pipeline": float(r["AverageNs"]) / 1e3,
+            "all": {x["Name"].split("(")[0].replace("ofdg::", ""): {"share": float(x["TotalDurationNs"]) / tot, "average_us": float(x["AverageNs"]) / 1e3} for x in rows}}
+
+
 def kernel_value(f, counter, which="compose"):
     name, out = None, {}
     for line in open(f):
@@ -36,6 +63,19 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_fetch_size_config*_background_pre
         "hbm_bytes_per_launch": fetch2 + write, "algorithmic_bytes_per_launch": 38 * W * H * B, "kernel_us_serialised": fe["dur_us"],
         "source": "committed PMC passes profiles/%s_pmc_fetch_write_size_config%d_background_prep_%d.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                   "runs of bench.py, tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note; counter collection serialises the kernels)" % (tag, cfg, bgp)}
+    # the whole step: every kernel's bytes at the L2s' memory side, summed (FETCH_SIZE x 2 + WRITE_SIZE per kernel)
+    fa, wa = all_kernels(f, "FETCH_SIZE"), all_kernels(f.replace("fetch", "write"), "WRITE_SIZE")
+    per_kernel = {k: int(fa.get(k, 0) * 1024 * 2 + wa.get(k, 0) * 1024) for k in sorted(set(fa) | set(wa))}
+    tj["config%d_background_prep_%d" % (cfg, bgp)]["whole_step"] = {
+        "hbm_bytes_per_step": sum(per_kernel.values()), "by_kernel": per_kernel,
+        "over_algorithmic": sum(per_kernel.values()) / (38 * W * H * B),
+        "source": "the same two passes, every kernel of the step: FETCH_SIZE x 2 + WRITE_SIZE, summed"}
+    stats = os.path.join(d, "kernel_stats.csv")
+    if cfg == 2 and bgp == 1 and os.path.exists(stats):
+        dk = dominant_kernel(stats)
+        if dk:
+            dk["source"] = "profiles/%s_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats over the default bench.py command)" % tag
+            tj["config%d_background_prep_%d" % (cfg, bgp)]["dominant_kernel_by_gpu_time"] = dk
     # the background preparation's kernel: its own HBM bytes from the same passes, its instruction counts from a third one
     fv = os.path.join(d, "pmc_valu_config%d_background_prep_%d.txt" % (cfg, bgp))
     if bgp and os.path.exists(fv):

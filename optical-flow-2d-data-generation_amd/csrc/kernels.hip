@@ -15,6 +15,7 @@
 //   closed form so that (edge, scanline) pairs can be processed independently.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/ofdg_detmath.h"
 #include "ofdg_device.h"
@@ -1802,8 +1803,11 @@ __device__ __forceinline__ uint2 rot_blend2(uint32_t cc0, uint32_t nc0, uint32_t
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int b = 8 * c;
-    const f32x2 Icc = {(float)((cc0 >> b) & 255u), (float)((cc1 >> b) & 255u)}, Inc = {(float)((nc0 >> b) & 255u), (float)((nc1 >> b) & 255u)};
-    const f32x2 Icn = {(float)((cn0 >> b) & 255u), (float)((cn1 >> b) & 255u)}, Inn = {(float)((nn0 >> b) & 255u), (float)((nn1 >> b) & 255u)};
+    f32x2 Icc = {(float)((cc0 >> b) & 255u), (float)((cc1 >> b) & 255u)}, Inc = {(float)((nc0 >> b) & 255u), (float)((nc1 >> b) & 255u)};
+    f32x2 Icn = {(float)((cn0 >> b) & 255u), (float)((cn1 >> b) & 255u)}, Inn = {(float)((nn0 >> b) & 255u), (float)((nn1 >> b) & 255u)};
+    // (opaque: differences of converted bytes are exact, and where two taps are visibly halves of ONE load the compiler subtracts
+    //  the bytes as integers and converts the differences - 30 more instructions per texel pair, none of them packed)
+    asm("" : "+v"(Icc), "+v"(Inc), "+v"(Icn), "+v"(Inn));
     const f32x2 t = ((Icc + Inn) - Icn) - Inc;
     const f32x2 val = (Icc + dx * ((Inc - Icc) + dy * t)) + dy * (Icn - Icc);
     out.x |= (uint32_t)(unsigned char)val.x << b;
@@ -2001,6 +2005,10 @@ constexpr int kPrepH = 32;                      // rows of B per tile (<= 64: la
 constexpr int kPrepG = 24;                      // rows of C sampled per group
 constexpr int kPrepRun = 16;                    // consecutive tiles that share an XCD (the kernel's blockIdx -> tile mapping)
 constexpr int kPrepCW = 90;                     // columns of C a tile needs at most: 64 * 4/3 + 2, even (texel pairs), + the margin of the crop size
+#ifndef OFDG_PREP_DIRS
+#define OFDG_PREP_DIRS 1
+#endif
+constexpr bool kPrepDirs = OFDG_PREP_DIRS != 0;  // the rotation specialised by a tile's side of the shift's mirror lines
 constexpr int kPrepMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // A tile's placement costs small dependent loads - which sample holds tile t (prefix of the samples' tile counts: LDS),
 // that sample's record, the four resize-table entries that bound the tile's piece of C - so a workgroup that has another
@@ -2011,6 +2019,8 @@ struct PrepTile {
   int cx0, cx1, cy0, cy1;   // texels of C it needs
   int fits;                 // ... which fit the LDS tile of C
   int inside;               // no mirroring / clamping anywhere in the tile: the per-texel range tests are skipped
+  int xdir, ydir;           // ... and where the tile lies relative to the shift's mirror lines: 1 = every tap right of / below the line
+                            // (pool index = i - shift), 2 = every tap left of / above it (pool index = shift - 1 - i), 0 = per lane
 };
 __host__ __device__ __forceinline__ bool prep_sample_fits(const DevBgPrep& q, int cap_cw, int cap_ch) { return q.cw >= 1 && q.ch >= 1 && q.cw <= cap_cw && q.ch <= cap_ch; }  // (caps <= 4/3 of the texture + 2)
 __host__ __device__ __forceinline__ int prep_tile_cols(const DevBgPrep& q) { return (q.rx1 - q.rx0 + kPrepW) / kPrepW; }
@@ -2030,6 +2040,7 @@ __device__ __forceinline__ void prep_finish_tile(const DevBgPrep& p, PrepTile& F
   // The usual tile: its crop coordinates need no mirroring and its four corners - so, the map being affine, all its texels
   // (a margin of one texel covers the rounding of the per-texel evaluation) - lie inside the source image: no per-texel tests.
   bool inside = F.fits && bgprep_shift_plain(p) && p.x0 + cx0 >= 0 && p.x0 + cx1 + 1 < p.rw && p.y0 + cy0 >= 0 && p.y0 + cy1 < p.rh;
+  int xdir = 0, ydir = 0;
   if (inside) {
     const float xa = __fsub_rn((float)(p.x0 + cx0), p.rw2), xb = __fsub_rn((float)(p.x0 + cx1 + 1), p.rw2);
     const float ya = __fsub_rn((float)(p.y0 + cy0), p.rh2), yb = __fsub_rn((float)(p.y0 + cy1), p.rh2);
@@ -2037,8 +2048,13 @@ __device__ __forceinline__ void prep_finish_tile(const DevBgPrep& p, PrepTile& F
     const float lo_x = fminf(fminf(ra.mx.x, ra.mx.y), fminf(rb.mx.x, rb.mx.y)), hi_x = fmaxf(fmaxf(ra.mx.x, ra.mx.y), fmaxf(rb.mx.x, rb.mx.y));
     const float lo_y = fminf(fminf(ra.my.x, ra.my.y), fminf(rb.my.x, rb.my.y)), hi_y = fmaxf(fmaxf(ra.my.x, ra.my.y), fmaxf(rb.my.x, rb.my.y));
     inside = lo_x >= 1.f && hi_x < (float)(p.pw - 2) && lo_y >= 1.f && hi_y < (float)(p.ph - 2);
+    // a tap's column is floor(mx) (and + 1), mx within [lo_x, hi_x] up to the rounding the margin of one texel covers
+    xdir = lo_x - 1.f >= (float)p.shx ? 1 : (hi_x + 3.f <= (float)p.shx ? 2 : 0);
+    ydir = lo_y - 1.f >= (float)p.shy ? 1 : (hi_y + 3.f <= (float)p.shy ? 2 : 0);
   }
   F.inside = __builtin_amdgcn_readfirstlane(inside ? 1 : 0);  // (wave-uniform by construction)
+  F.xdir = __builtin_amdgcn_readfirstlane(inside ? xdir : 0);
+  F.ydir = __builtin_amdgcn_readfirstlane(inside ? ydir : 0);
 }
 // ---- the resize passes in exact INTEGER arithmetic --------------------------------------------------------------------------
 // Enlarging: CImg evaluates (T)((1 - a) v1 + a v2) in double.  Where the weight a has at most 45 fractional bits - every
@@ -2102,7 +2118,11 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) {
 }
 // bgprep_rot_inside2 in two halves - the four 8-byte gathers of a texel pair requested, and the pair blended - so that the
 // next pair's gathers can be in flight while this one is blended
+// kXD / kYD: the tile's side of the shift's mirror lines when it is the same for every tap (PrepTile.xdir / ydir; 0: per lane).
+// Right of the line a tap's pool column is i - shx and its neighbour's the next one: the 8-byte load IS (cc, nc); left of it the
+// columns descend (shx - 1 - i): the load at the neighbour's column is (nc, cc).  Rows likewise (y + 1 is the row below or above).
 struct RotTaps { uint2 a0, a1, b0, b1; f32x2 dx, dy; int ja, jb; };
+template <int kXD = 0, int kYD = 0>
 __device__ __forceinline__ RotTaps rot_issue(const DevBgPrep& p, const RotPair& r) {
   const char* imgc = (const char*)p.image_addr;
   const uint32_t upw = (uint32_t)p.pw;
@@ -2111,15 +2131,27 @@ __device__ __forceinline__ RotTaps rot_issue(const DevBgPrep& p, const RotPair& 
   RotTaps t;
   t.dx = mx - f32x2{(float)x0i, (float)x1i};
   t.dy = my - f32x2{(float)y0i, (float)y1i};
-  auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
   auto pair = [&](int row, int col) { return gload2(imgc, (__umul24((uint32_t)row, upw) + (uint32_t)col) * 4u); };
   t.ja = x0i - p.shx; t.jb = x1i - p.shx;
-  const int basea = t.ja >= 0 ? t.ja : max(-t.ja - 2, 0), baseb = t.jb >= 0 ? t.jb : max(-t.jb - 2, 0);
-  t.a0 = pair(sh(y0i, p.shy), basea); t.a1 = pair(sh(y0i + 1, p.shy), basea);
-  t.b0 = pair(sh(y1i, p.shy), baseb); t.b1 = pair(sh(y1i + 1, p.shy), baseb);
+  int basea, baseb;
+  if (kXD == 1) { basea = t.ja; baseb = t.jb; }
+  else if (kXD == 2) { basea = -t.ja - 2; baseb = -t.jb - 2; }
+  else { basea = t.ja >= 0 ? t.ja : max(-t.ja - 2, 0); baseb = t.jb >= 0 ? t.jb : max(-t.jb - 2, 0); }
+  int ra0, ra1, rb0, rb1;  // pool rows of texel a's and b's upper and lower taps
+  if (kYD == 1) { ra0 = y0i - p.shy; ra1 = ra0 + 1; rb0 = y1i - p.shy; rb1 = rb0 + 1; }
+  else if (kYD == 2) { ra0 = p.shy - 1 - y0i; ra1 = ra0 - 1; rb0 = p.shy - 1 - y1i; rb1 = rb0 - 1; }
+  else {
+    auto sh = [](int i, int s_) { const int j = i - s_; return j < 0 ? -j - 1 : j; };
+    ra0 = sh(y0i, p.shy); ra1 = sh(y0i + 1, p.shy); rb0 = sh(y1i, p.shy); rb1 = sh(y1i + 1, p.shy);
+  }
+  t.a0 = pair(ra0, basea); t.a1 = pair(ra1, basea);
+  t.b0 = pair(rb0, baseb); t.b1 = pair(rb1, baseb);
   return t;
 }
+template <int kXD = 0>
 __device__ __forceinline__ uint2 rot_finish(const RotTaps& t) {
+  if (kXD == 1) return rot_blend2(t.a0.x, t.a0.y, t.a1.x, t.a1.y, t.b0.x, t.b0.y, t.b1.x, t.b1.y, t.dx, t.dy);
+  if (kXD == 2) return rot_blend2(t.a0.y, t.a0.x, t.a1.y, t.a1.x, t.b0.y, t.b0.x, t.b1.y, t.b1.x, t.dx, t.dy);
   const bool reva = t.ja < 0, swapa = t.ja < -1, revb = t.jb < 0, swapb = t.jb < -1;
   const uint32_t cc0 = swapa ? t.a0.y : t.a0.x, nc0 = reva ? t.a0.x : t.a0.y, cn0 = swapa ? t.a1.y : t.a1.x, nn0 = reva ? t.a1.x : t.a1.y;
   const uint32_t cc1 = swapb ? t.b0.y : t.b0.x, nc1 = revb ? t.b0.x : t.b0.y, cn1 = swapb ? t.b1.y : t.b1.x, nn1 = revb ? t.b1.x : t.b1.y;
@@ -2299,22 +2331,33 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
         // ---- rotation: C(cx0 + 2 pi .., cy0 + g0 + jj), texel pairs ----
         if (cur.inside) {
           // two rounds in flight: the next round's four gathers are requested before this round's texels are blended
-          auto issue = [&](int k) {
-            const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-            const int pi = k - jj * pairs;
-            const int xi = p.x0 + cx0 + 2 * pi;
-            return rot_issue(p, bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + g0 + jj), p.rh2)));
+          auto rotate = [&](auto xd, auto yd) {
+            constexpr int kXD = decltype(xd)::value, kYD = decltype(yd)::value;
+            auto issue = [&](int k) {
+              const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+              const int pi = k - jj * pairs;
+              const int xi = p.x0 + cx0 + 2 * pi;
+              return rot_issue<kXD, kYD>(p, bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + g0 + jj), p.rh2)));
+            };
+            RotTaps tcur = issue(min(lane, items - 1));
+            for (int k = lane; k < items; k += 64) {
+              const int kn = k + 64;
+              RotTaps tnext = tcur;
+              if (kn < items) tnext = issue(kn);
+              const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
+              const int pi = k - jj * pairs;
+              *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = rot_finish<kXD>(tcur);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
+              tcur = tnext;
+            }
           };
-          RotTaps tcur = issue(min(lane, items - 1));
-          for (int k = lane; k < items; k += 64) {
-            const int kn = k + 64;
-            RotTaps tnext = tcur;
-            if (kn < items) tnext = issue(kn);
-            const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
-            const int pi = k - jj * pairs;
-            *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = rot_finish(tcur);  // (the odd texel beyond an odd-width region is inside too; nobody reads it)
-            tcur = tnext;
-          }
+          // (a tile lies on ONE side of the shift's mirror lines unless a line crosses it: the per-lane selects and mirrored
+          //  indices of the general form drop out - 140 instead of 168 vector instructions per texel pair)
+          using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+          if (kPrepDirs && cur.xdir == 1 && cur.ydir == 1) rotate(I1{}, I1{});
+          else if (kPrepDirs && cur.xdir == 2 && cur.ydir == 1) rotate(I2{}, I1{});
+          else if (kPrepDirs && cur.xdir == 1 && cur.ydir == 2) rotate(I1{}, I2{});
+          else if (kPrepDirs && cur.xdir == 2 && cur.ydir == 2) rotate(I2{}, I2{});
+          else rotate(I0{}, I0{});
         } else {
           for (int k = lane; k < items; k += 64) {
             const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);

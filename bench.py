@@ -584,13 +584,13 @@ def main():
             "hbm_gbs_whole_step": step_gbs,
         }
         if prep_ms is not None:
-            # The step's other heavy kernel is bound by neither HBM nor MFMA (the latency of a wave's dependent chain - gathers, LDS, stores - per tile, and
-            # what the co-running kernels leave of the memory pipeline); reported: its launch, and its vector instructions against
+            # The step's other heavy kernel is bound by neither HBM nor MFMA (the instruction issue of its own waves - 6 300 instructions per
+            # 64 x 32 tile - and what the co-running kernels leave of the wave slots); reported: its launch, and its vector instructions against
             # the chip's issue rate - 256 CUs x 4 SIMDs, one wave64 vector instruction per 2 cycles, 2.4 GHz - as a utilisation.
             # Instruction counts per launch come from the committed PMC pass of this configuration (null without one).
             valu = prep_pmc.get("valu_instructions_per_launch") if prep_pmc else None
             out["background_prep_kernel"] = {
-                "kernel": (prep_pmc or {}).get("kernel", "bgprep_stream_kernel"), "bound": "latency of a wave's dependent chain per tile (neither hbm nor mfma)",
+                "kernel": (prep_pmc or {}).get("kernel", "bgprep_stream_kernel"), "bound": "instruction issue of its own waves: 73 % of a wave's life is issue, 27 % s_waitcnt (neither hbm nor mfma; DESIGN.md section 4)",
                 "kernel_ms": prep_ms, "kernel_ms_alone": alone["background_prep"],
                 "valu_instructions_per_launch": valu, "peak": VALU_PEAK_GINST, "unit": "G wave instructions/s",
                 "achieved": valu / (prep_ms * 1e-3) / 1e9 if valu else None,

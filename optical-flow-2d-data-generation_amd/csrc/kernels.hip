@@ -2008,6 +2008,10 @@ constexpr int kPrepCW = 90;                     // columns of C a tile needs at 
 #ifndef OFDG_PREP_DIRS
 #define OFDG_PREP_DIRS 1
 #endif
+#ifndef OFDG_PREP_FAST_RESIZE
+#define OFDG_PREP_FAST_RESIZE 1
+#endif
+constexpr bool kPrepFastResize = OFDG_PREP_FAST_RESIZE != 0;  // the resize passes specialised by a tile's case (both axes enlarge / shrink)
 constexpr bool kPrepDirs = OFDG_PREP_DIRS != 0;  // the rotation specialised by a tile's side of the shift's mirror lines
 constexpr int kPrepMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // A tile's placement costs small dependent loads - which sample holds tile t (prefix of the samples' tile counts: LDS),
@@ -2320,6 +2324,11 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
       const int xi1 = (TW > p.cw ? min(ex.u0 + 1, p.cw - 1) : min(ex.u0 + 1, cx1)) - cx0, xi2 = min(ex.u0 + 2, cx1) - cx0;
       const int ylastv = axis_last(p.ch, TH, ey.u0, ey.u1, ey.u2);
       uint32_t* Bs = B + (size_t)cur.s * TW * TH;
+      // the tile's resize case (uniform): both axes enlarge with exact weights in every column and row of the tile / both shrink
+      // with 24-bit quotients
+      const bool y_exact = __ballot(lane <= by1 - by0 && TH > p.ch && !(ey.u2 >> 31)) == 0ull;
+      const bool fast_enlarge = TW > p.cw && TH > p.ch && x_exact && y_exact;
+      const bool fast_shrink = TW < p.cw && TH < p.ch && xdiv24 && ydiv24;
       uint32_t m0 = 0, m1 = 0, m2 = 0;  // M(x, j - 2), M(x, j - 1), M(x, j)
       int y = by0;                      // the next row of B to emit ...
       int ylast = __builtin_amdgcn_readlane(ylastv, 0);  // ... and the last row of M it needs
@@ -2371,26 +2380,64 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
         }
         __syncthreads();  // (one wave: the rows are complete before its lanes read their neighbours' texels)
         // ---- X resize into the register window, and every row of B that is complete with it ----
-        for (int r = 0; r < rows; ++r) {
-          const int j = cy0 + g0 + r;
-          m0 = m1; m1 = m2;
-          m2 = have_x ? axis_texel(p.cw, TW, x, ex.u1, ex.u2, x_exact, s_c[r][xi0], s_c[r][xi1], s_c[r][xi2], xdiv, xdiv24, T.alpha_x) : 0u;
+        // The general loop decides per row what its axis does (enlarge with an exact weight / in double, copy, shrink with a 24-bit
+        // or a 32-bit quotient): a chain of uniform branches per row of C and per row of B.  A sample's zoom makes BOTH axes
+        // enlarge (zoom > 1) or BOTH shrink (zoom < 1), and all weights of a tile compose can see are exact: the two loops
+        // below are those two cases with nothing to decide inside (round 6; the resize passes are 40 % of the kernel's time).
+        auto emit_rows = [&](int j, auto value) {  // every row y of B whose last source row is j
           while (y <= by1 && ylast <= j) {
             const int rr = y - by0;
             const int v0 = __builtin_amdgcn_readlane(ey.u0, rr);
             const uint32_t v1 = (uint32_t)__builtin_amdgcn_readlane((int)ey.u1, rr), v2 = (uint32_t)__builtin_amdgcn_readlane((int)ey.u2, rr);
-            // rows v0, v0 + 1, v0 + 2 of M (uniform), clamped to j = the row's last source row: the window holds j - 2 .. j
-            // (enlarging: j is v0 + 1, or v0 in the last row of M; shrinking: v0 + 2, or v0 + 1 where the third tap has no weight)
-            const int dj = j - v0;
-            uint32_t t0 = m2, t1 = m2;
-            if (dj >= 2) { t0 = m0; t1 = m1; } else if (dj == 1) { t0 = m1; }
-            const uint32_t v = axis_texel(p.ch, TH, y, v1, v2, (v2 >> 31) != 0u, t0, t1, m2, ydiv, ydiv24, T.alpha_y);
+            const uint32_t v = value(j - v0, v1, v2);
             // (non-temporal like compose's planes: written once here, read once by the next kernel - +3.5 % on the step over plain
             //  stores, profiles/r05_ab_nt_intermediate_stores.txt; raster's coverage bytes: no difference)
             if (have_x) __builtin_nontemporal_store(v, &Bs[(uint32_t)(y * TW + x)]);
             ++y;
             ylast = y <= by1 ? __builtin_amdgcn_readlane(ylastv, y - by0) : 0x7fffffff;
           }
+        };
+        if (kPrepFastResize && fast_enlarge) {
+          const int xa1 = (int)ex.u1, xa0 = (int)(ex.u2 & 0x7fffffffu);
+          for (int r = 0; r < rows; ++r) {
+            const uint32_t t0 = s_c[r][xi0], t1 = s_c[r][xi1];
+            m1 = m2;
+            m2 = enlarge_texel_fix(t0, t1, xa1, xa0);
+            // rows v0, v0 + 1 of M: the row's last source row j is v0 + 1, or v0 in the last row of M
+            emit_rows(cy0 + g0 + r, [&](int dj, uint32_t v1, uint32_t v2) { return enlarge_texel_fix(dj >= 1 ? m1 : m2, m2, (int)v1, (int)(v2 & 0x7fffffffu)); });
+          }
+        } else if (kPrepFastResize && fast_shrink) {
+          const uint32_t xd0 = ex.u1, xd1 = ex.u2, xd2 = (uint32_t)p.cw - ex.u1 - ex.u2;
+          auto shrink24 = [](uint32_t t0, uint32_t t1, uint32_t t2, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t mdiv) {
+            uint32_t acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              acc[c] = __umul24((t2 >> (8 * c)) & 255u, d2) + (__umul24((t1 >> (8 * c)) & 255u, d1) + __umul24((t0 >> (8 * c)) & 255u, d0));
+            return mulhi_u24(acc[0], mdiv) | (mulhi_u24(acc[1], mdiv) << 8) | (mulhi_u24(acc[2], mdiv) << 16);
+          };
+          for (int r = 0; r < rows; ++r) {
+            const uint32_t t0 = s_c[r][xi0], t1 = s_c[r][xi1], t2 = s_c[r][xi2];
+            m0 = m1; m1 = m2;
+            m2 = shrink24(t0, t1, t2, xd0, xd1, xd2, xdiv);
+            // rows v0 .. v0 + 2 of M, clamped to j: j is v0 + 2, or v0 + 1 where the third tap has no weight
+            emit_rows(cy0 + g0 + r, [&](int dj, uint32_t v1, uint32_t v2) {
+              const uint32_t t0y = dj >= 2 ? m0 : (dj == 1 ? m1 : m2), t1y = dj >= 2 ? m1 : m2;
+              return shrink24(t0y, t1y, m2, v1, v2, (uint32_t)p.ch - v1 - v2, ydiv);
+            });
+          }
+        } else {
+        for (int r = 0; r < rows; ++r) {
+          const int j = cy0 + g0 + r;
+          m0 = m1; m1 = m2;
+          m2 = have_x ? axis_texel(p.cw, TW, x, ex.u1, ex.u2, x_exact, s_c[r][xi0], s_c[r][xi1], s_c[r][xi2], xdiv, xdiv24, T.alpha_x) : 0u;
+          emit_rows(j, [&](int dj, uint32_t v1, uint32_t v2) {
+            // rows v0, v0 + 1, v0 + 2 of M (uniform), clamped to j = the row's last source row: the window holds j - 2 .. j
+            // (enlarging: j is v0 + 1, or v0 in the last row of M; shrinking: v0 + 2, or v0 + 1 where the third tap has no weight)
+            uint32_t t0 = m2, t1 = m2;
+            if (dj >= 2) { t0 = m0; t1 = m1; } else if (dj == 1) { t0 = m1; }
+            return axis_texel(p.ch, TH, y, v1, v2, (v2 >> 31) != 0u, t0, t1, m2, ydiv, ydiv24, T.alpha_y);
+          });
+        }
         }
         __syncthreads();  // (the next group overwrites the rows)
       }

@@ -2012,6 +2012,9 @@ constexpr int kPrepCW = 90;                     // columns of C a tile needs at 
 #define OFDG_PREP_FAST_RESIZE 1
 #endif
 constexpr bool kPrepFastResize = OFDG_PREP_FAST_RESIZE != 0;  // the resize passes specialised by a tile's case (both axes enlarge / shrink)
+#ifndef OFDG_PREP_ROUND2
+#define OFDG_PREP_ROUND2 1
+#endif
 constexpr bool kPrepDirs = OFDG_PREP_DIRS != 0;  // the rotation specialised by a tile's side of the shift's mirror lines
 constexpr int kPrepMaxSamples = 512;            // (the counter sampler's batch limit; ofdg_api.hip falls back to the two-kernel form beyond)
 // A tile's placement costs small dependent loads - which sample holds tile t (prefix of the samples' tile counts: LDS),
@@ -2348,6 +2351,19 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
               const int xi = p.x0 + cx0 + 2 * pi;
               return rot_issue<kXD, kYD>(p, bgprep_rot_coords(p, __fsub_rn((float)xi, p.rw2), __fsub_rn((float)(xi + 1), p.rw2), __fsub_rn((float)(p.y0 + cy0 + g0 + jj), p.rh2)));
             };
+#if OFDG_PREP_ROUND2
+            // a round = TWO pairs per lane (k and k + 64), all eight gathers requested before the first wait: one exposed round trip
+            // per four texels, uniform control flow (the last round's lanes beyond the end repeat the last pair), no set of taps copied
+            for (int k0 = 0; k0 < items; k0 += 128) {
+              const int ka = min(k0 + lane, items - 1), kb = min(k0 + 64 + lane, items - 1);
+              const RotTaps ta = issue(ka);
+              const RotTaps tb = issue(kb);
+              const int ja = (int)(__umul24((uint32_t)ka, inv_pairs) >> 20), jb = (int)(__umul24((uint32_t)kb, inv_pairs) >> 20);
+              *reinterpret_cast<uint2*>(&s_c[ja][2 * (ka - ja * pairs)]) = rot_finish<kXD>(ta);
+              *reinterpret_cast<uint2*>(&s_c[jb][2 * (kb - jb * pairs)]) = rot_finish<kXD>(tb);
+            }
+          };
+#else
             RotTaps tcur = issue(min(lane, items - 1));
             for (int k = lane; k < items; k += 64) {
               const int kn = k + 64;
@@ -2359,6 +2375,7 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
               tcur = tnext;
             }
           };
+#endif
           // (a tile lies on ONE side of the shift's mirror lines unless a line crosses it: the per-lane selects and mirrored
           //  indices of the general form drop out - 140 instead of 168 vector instructions per texel pair)
           using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;

@@ -2385,14 +2385,18 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
           else if (kPrepDirs && cur.xdir == 2 && cur.ydir == 2) rotate(I2{}, I2{});
           else rotate(I0{}, I0{});
         } else {
+          // (the rare general form - mirrored crop coordinates, modulo, clamps: an opaque copy of the record's sizes, so that nothing it
+          //  derives from them - floats, doubles of the image size - is computed in front of the tile and held through the fast forms)
+          DevBgPrep q = p;
+          asm volatile("" : "+s"(q.pw), "+s"(q.ph), "+s"(q.rw), "+s"(q.rh), "+s"(q.shx), "+s"(q.shy));
           for (int k = lane; k < items; k += 64) {
             const int jj = (int)(__umul24((uint32_t)k, inv_pairs) >> 20);
             const int pi = k - jj * pairs;
             const int i = cx0 + 2 * pi, j = cy0 + g0 + jj;
             const bool second = i + 1 <= cx1;
-            const int rx0 = mirror_index(p.x0 + i, p.rw), rx1 = mirror_index(p.x0 + i + 1, p.rw), ry = mirror_index(p.y0 + j, p.rh);
-            const float xc0 = __fsub_rn((float)rx0, p.rw2), xc1 = __fsub_rn((float)rx1, p.rw2), yc = __fsub_rn((float)ry, p.rh2);
-            *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_sample2(p, xc0, xc1, yc, second);
+            const int rx0 = mirror_index(q.x0 + i, q.rw), rx1 = mirror_index(q.x0 + i + 1, q.rw), ry = mirror_index(q.y0 + j, q.rh);
+            const float xc0 = __fsub_rn((float)rx0, q.rw2), xc1 = __fsub_rn((float)rx1, q.rw2), yc = __fsub_rn((float)ry, q.rh2);
+            *reinterpret_cast<uint2*>(&s_c[jj][2 * pi]) = bgprep_rot_sample2(q, xc0, xc1, yc, second);
           }
         }
         __syncthreads();  // (one wave: the rows are complete before its lanes read their neighbours' texels)
@@ -2443,16 +2447,18 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
             });
           }
         } else {
+        int xg = x, cwg = p.cw, chg = p.ch;  // (opaque: see the general rotation above)
+        asm volatile("" : "+v"(xg), "+s"(cwg), "+s"(chg));
         for (int r = 0; r < rows; ++r) {
           const int j = cy0 + g0 + r;
           m0 = m1; m1 = m2;
-          m2 = have_x ? axis_texel(p.cw, TW, x, ex.u1, ex.u2, x_exact, s_c[r][xi0], s_c[r][xi1], s_c[r][xi2], xdiv, xdiv24, T.alpha_x) : 0u;
+          m2 = have_x ? axis_texel(cwg, TW, xg, ex.u1, ex.u2, x_exact, s_c[r][xi0], s_c[r][xi1], s_c[r][xi2], xdiv, xdiv24, T.alpha_x) : 0u;
           emit_rows(j, [&](int dj, uint32_t v1, uint32_t v2) {
             // rows v0, v0 + 1, v0 + 2 of M (uniform), clamped to j = the row's last source row: the window holds j - 2 .. j
             // (enlarging: j is v0 + 1, or v0 in the last row of M; shrinking: v0 + 2, or v0 + 1 where the third tap has no weight)
             uint32_t t0 = m2, t1 = m2;
             if (dj >= 2) { t0 = m0; t1 = m1; } else if (dj == 1) { t0 = m1; }
-            return axis_texel(p.ch, TH, y, v1, v2, (v2 >> 31) != 0u, t0, t1, m2, ydiv, ydiv24, T.alpha_y);
+            return axis_texel(chg, TH, y, v1, v2, (v2 >> 31) != 0u, t0, t1, m2, ydiv, ydiv24, T.alpha_y);
           });
         }
         }

@@ -315,6 +315,11 @@ int ofdg_debug_item_count(ofdg_ctx* ctx);
  * (bgprep_stream_kernel) walked for that batch and the number of workgroups that shared them grid-stride (0 tiles: the batch took
  * another form of the preparation).  Tests use it to make sure they reach a workgroup's 2nd, 3rd ... tile. */
 int ofdg_debug_bgprep_tiles(ofdg_ctx* ctx, int* tiles, int* workgroups);
+/* Tiles of bgprep_stream_kernel since the last call, by the form that rendered them: counts9[rotation + 3 * resize], rotation
+ * 0 = general (mirrored / clamped crop coordinates), 1 = inside the image, 2 = inside and specialised by the side of the shift's
+ * mirror lines; resize 0 = decided per row, 1 = both axes enlarge, 2 = both shrink.  The first call switches the counting on and
+ * returns zeros.  (Texture::getRandomizedCrop, DG:87-109: which of its branches the batch took.) */
+int ofdg_debug_bgprep_paths(ofdg_ctx* ctx, unsigned* counts9);
 /* Exhaustive device evaluation of the per-byte formulas: composite add / subtract
  * [u*256+v] (DG:606, 626), AA mask byte [c], draw_image blend [d*256+m] for s=s_fixed. */
 int ofdg_debug_tables(ofdg_ctx* ctx, uint8_t* add_tbl, uint8_t* sub_tbl, uint8_t* aa_tbl,

@@ -90,7 +90,7 @@ EXPORTS = [
     "ofdg_default_params", "ofdg_create", "ofdg_destroy", "ofdg_last_error", "ofdg_ctx_info",
     "ofdg_host_bg_prep", "ofdg_ctx_params", "ofdg_pool_alloc_mixed", "ofdg_pool_upload_mixed", "ofdg_pool_synthetic", "ofdg_pool_alloc", "ofdg_pool_upload", "ofdg_pool_download", "ofdg_pool_info", "ofdg_pool_device",
     "ofdg_sample", "ofdg_render", "ofdg_render_resident", "ofdg_upload_slot", "ofdg_render_slot", "ofdg_forward", "ofdg_shard_first_index", "ofdg_synchronize", "ofdg_stream", "ofdg_get_step", "ofdg_set_step",
-    "ofdg_debug_rasterize", "ofdg_debug_rasterize_path", "ofdg_debug_dda_rows", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_bgprep_tiles", "ofdg_debug_tables", "ofdg_debug_detmath",
+    "ofdg_debug_rasterize", "ofdg_debug_rasterize_path", "ofdg_debug_dda_rows", "ofdg_debug_coverage", "ofdg_debug_num_shapes", "ofdg_debug_item_count", "ofdg_debug_bgprep_tiles", "ofdg_debug_bgprep_paths", "ofdg_debug_tables", "ofdg_debug_detmath",
     "ofdg_set_profiling", "ofdg_kernel_ms",
     "ofdg_forward_counter", "ofdg_sample_counter", "ofdg_warp_generate", "ofdg_warp_upload", "ofdg_warp_info", "ofdg_warp_download", "ofdg_host_displacers",
     "ofdg_host_sampler_create", "ofdg_host_sampler_next", "ofdg_host_sampler_destroy", "ofdg_host_realize",
@@ -157,6 +157,7 @@ def lib():
         L.ofdg_debug_num_shapes.argtypes = [vp, i32]
         L.ofdg_debug_tables.argtypes = [vp, vp, vp, vp, vp, i32]
         L.ofdg_debug_bgprep_tiles.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        L.ofdg_debug_bgprep_paths.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.ofdg_debug_detmath.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
         L.ofdg_set_profiling.argtypes = [vp, i32]
         L.ofdg_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
@@ -487,6 +488,13 @@ class Generator:
         t, w = C.c_int(0), C.c_int(0)
         self._check(lib().ofdg_debug_bgprep_tiles(self.h, C.byref(t), C.byref(w)))
         return t.value, w.value
+
+    def debug_bgprep_paths(self):
+        """Tiles of the one-launch preparation since the last call by form: a 3 x 3 list [resize][rotation] (see include/ofdg.h);
+        the first call switches the counting on."""
+        c = (C.c_uint32 * 9)()
+        self._check(lib().ofdg_debug_bgprep_paths(self.h, c))
+        return [[int(c[3 * r + k]) for k in range(3)] for r in range(3)]
 
     def debug_tables(self, s_fixed=200):
         import numpy as np

@@ -2227,8 +2227,12 @@ __device__ __forceinline__ uint32_t axis_texel(int n, int sdim, int k, uint32_t 
   }
   return out;
 }
+// paths (diagnostics, nullptr in production): 9 counters of tiles by the form that rendered them, [rotation + 3 * resize]: rotation
+// 0 = general (off the `inside` fast path), 1 = inside, side of the mirror lines decided per lane, 2 = inside and specialised by
+// side; resize 0 = decided per row, 1 = both axes enlarge, 2 = both shrink
 __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __restrict__ prep, DevResizeTabs T, int W, int H, int n_samples,
-                                                           int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err) {
+                                                           int cap_cw, int cap_ch, uint32_t* __restrict__ B, uint32_t* __restrict__ err,
+                                                           uint32_t* __restrict__ paths) {
   __shared__ uint32_t s_c[kPrepG][kPrepCW];
   extern __shared__ int s_first[];  // [n_samples + 1]: tiles of the samples before sample i
   const int TW = 2 * W, TH = 2 * H, lane = threadIdx.x;
@@ -2332,6 +2336,8 @@ __global__ __launch_bounds__(64) void bgprep_stream_kernel(const DevBgPrep* __re
       const bool y_exact = __ballot(lane <= by1 - by0 && TH > p.ch && !(ey.u2 >> 31)) == 0ull;
       const bool fast_enlarge = TW > p.cw && TH > p.ch && x_exact && y_exact;
       const bool fast_shrink = TW < p.cw && TH < p.ch && xdiv24 && ydiv24;
+      if (paths && lane == 0)
+        atomicAdd(&paths[(cur.inside ? ((kPrepDirs && cur.xdir && cur.ydir) ? 2 : 1) : 0) + 3 * (kPrepFastResize ? (fast_enlarge ? 1 : fast_shrink ? 2 : 0) : 0)], 1u);
       uint32_t m0 = 0, m1 = 0, m2 = 0;  // M(x, j - 2), M(x, j - 1), M(x, j)
       int y = by0;                      // the next row of B to emit ...
       int ylast = __builtin_amdgcn_readlane(ylastv, 0);  // ... and the last row of M it needs

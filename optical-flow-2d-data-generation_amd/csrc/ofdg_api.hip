@@ -56,6 +56,7 @@ struct ofdg_ctx {
   ofdg_params prm;
   std::string err;
   std::string info;
+  uint32_t* d_prep_paths = nullptr;  // diagnostics: tiles of bgprep_stream_kernel by form (ofdg_debug_bgprep_paths switches it on)
   // texture pool
   uint32_t* pool = nullptr;
   int pool_n = 0, pool_w = 0, pool_h = 0;
@@ -384,6 +385,7 @@ void ofdg_destroy(ofdg_ctx* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
   if (c->pool) (void)hipFree(c->pool);
+  if (c->d_prep_paths) (void)hipFree(c->d_prep_paths);
   if (c->pool_fg) (void)hipFree(c->pool_fg);
   if (c->pool_bg) (void)hipFree(c->pool_bg);
   for (uint32_t* im : c->mixed_images) if (im) (void)hipFree(im);
@@ -1170,7 +1172,8 @@ static int prepare_backgrounds(ofdg_ctx* c, ofdg_ctx::Slot& sl, int n, bool reco
   }
   const DevResizeTabs T{c->d_bg_at_x.p, c->d_bg_alpha_x.p, c->d_bg_at_y.p, c->d_bg_alpha_y.p};
   if (fusable && n <= kPrepMaxSamples) {
-    hipExtLaunchKernelGGL(bgprep_stream_kernel, dim3(kPrepGrid), dim3(64), (size_t)(n + 1) * sizeof(int), s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err);
+    hipExtLaunchKernelGGL(bgprep_stream_kernel, dim3(kPrepGrid), dim3(64), (size_t)(n + 1) * sizeof(int), s, nullptr, stop, 0, sl.d_bgprep.p, T, W, H, n, cap_cw, cap_ch, sl.d_bgtex.p, err,
+                          c->d_prep_paths);
     HIP_OK(c, hipGetLastError());
     return OFDG_OK;
   }
@@ -1866,6 +1869,21 @@ int ofdg_debug_bgprep_tiles(ofdg_ctx* c, int* tiles, int* workgroups) {
   HIP_OK(c, hipMemcpy(rec.data(), sl.d_bgprep.p, rec.size() * sizeof(DevBgPrep), hipMemcpyDeviceToHost));
   for (const DevBgPrep& q : rec)
     if (prep_sample_fits(q, cap_cw, cap_ch)) *tiles += prep_tile_cols(q) * prep_tile_rows(q);
+  return OFDG_OK;
+}
+
+// Which forms of bgprep_stream_kernel rendered the tiles since the last call (the first call switches the counting on and returns
+// zeros): counts[rotation + 3 * resize], see the kernel.  A guard for the tests: parity cannot tell a batch whose tiles all fell
+// back to the general forms from one that took the fast ones.
+int ofdg_debug_bgprep_paths(ofdg_ctx* c, unsigned* counts9) {
+  if (!c || !counts9) return OFDG_EINVAL;
+  HIP_OK(c, hipDeviceSynchronize());
+  if (!c->d_prep_paths) {
+    HIP_OK(c, hipMalloc((void**)&c->d_prep_paths, 9 * sizeof(uint32_t)));
+    HIP_OK(c, hipMemset(c->d_prep_paths, 0, 9 * sizeof(uint32_t)));
+  }
+  HIP_OK(c, hipMemcpy(counts9, c->d_prep_paths, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_OK(c, hipMemset(c->d_prep_paths, 0, 9 * sizeof(uint32_t)));
   return OFDG_OK;
 }
 

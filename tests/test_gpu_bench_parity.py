@@ -178,3 +178,30 @@ def test_host_sampled_batch_with_background_preparation_matches_oracle(ofdg, ora
     which = [0, B // 2, B - 2, B - 1] if subset_only() else range(B)
     check_samples(ofdg, oracle, g, prm, tasks, bps, n, got, which, cfg["pool"][0], detmath=False, flow_ulp=0)  # (libm arithmetic: the host path's own)
     g.close()
+
+
+def test_bench_batches_take_the_fast_forms_of_the_preparation(ofdg):
+    """Parity cannot tell a batch whose tiles all fell back to the preparation's general forms (mirrored crop coordinates, resize
+    decided per row) from one that took the fast ones - the kernel counts its tiles by form (ofdg_debug_bgprep_paths): of config
+    2's batch at least 85 % must take the rotation specialised by the side of the shift's mirror lines (a mirror line crosses about
+    one tile in ten) AND one of the two specialised resize loops (getRandomizedCrop's zoom makes both axes enlarge or both shrink,
+    DG:87-109), and every tile is counted once."""
+    import bench
+    torch = pytest.importorskip("torch")
+    cfg = bench.CONFIGS[2]
+    B = cfg["batch"]
+    g, prm, _ = bench_generator(ofdg, bench, cfg, sampler=1)
+    got = ofdg.alloc_outputs(B, cfg["H"], cfg["W"])
+    assert sum(map(sum, g.debug_bgprep_paths())) == 0      # (switches the counting on)
+    fast = total = 0
+    for step in (2, 7, 11):
+        g.forward_counter(step * B, B, *got, ofdg.STREAM_OWN)
+        g.synchronize()
+        torch.cuda.synchronize()
+        tiles, _ = g.debug_bgprep_tiles()
+        paths = g.debug_bgprep_paths()
+        assert sum(map(sum, paths)) == tiles, (paths, tiles)
+        fast += paths[1][2] + paths[2][2]
+        total += tiles
+    assert fast >= 0.85 * total, "only %d of %d tiles took the specialised forms" % (fast, total)
+    g.close()

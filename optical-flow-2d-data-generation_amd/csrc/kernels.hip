@@ -1096,6 +1096,9 @@ __device__ __forceinline__ void taps_finish(const Taps4& T, uint32_t out[kPx]) {
 // of a visit costs the fourth wave (149 VGPRs) and more than it saves.
 // --------------------------------------------------------------------------
 constexpr int kPre = 2;  // objects of a block whose header / coverage / record are fetched ahead of their visit
+#ifndef OFDG_DEFORM_FENCE
+#define OFDG_DEFORM_FENCE 1
+#endif
 
 template <bool kPow2, bool kDeform = false>
 __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samples, const unsigned long long* __restrict__ blockmask,
@@ -1261,12 +1264,12 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
   }
 
   // ---- foreground objects in z-order ----
-  WarpGeom g;
-  g.tw = W; g.th = H; g.tw2 = 2 * W; g.th2 = 2 * H;
-  g.mx2 = ((g.tw2 & (g.tw2 - 1)) == 0) ? g.tw2 - 1 : -1;
-  g.my2 = ((g.th2 & (g.th2 - 1)) == 0) ? g.th2 - 1 : -1;
-  g.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
-  g.pitch = fg_pitch;
+  WarpGeom g_frame;
+  g_frame.tw = W; g_frame.th = H; g_frame.tw2 = 2 * W; g_frame.th2 = 2 * H;
+  g_frame.mx2 = ((g_frame.tw2 & (g_frame.tw2 - 1)) == 0) ? g_frame.tw2 - 1 : -1;
+  g_frame.my2 = ((g_frame.th2 & (g_frame.th2 - 1)) == 0) ? g_frame.th2 - 1 : -1;
+  g_frame.nshift = ((W & (W - 1)) == 0) ? (31 - __clz(W)) : -1;
+  g_frame.pitch = fg_pitch;
   int vi = 0;  // visit number
   while (omask) {
     const int oi = __ffsll((long long)omask);  // 1-based == index into objs[]
@@ -1276,6 +1279,21 @@ __device__ __forceinline__ void compose_rigid(const DevSample* __restrict__ samp
     //  hoisted out of the loop, where they would hold two dozen registers across every visit)
     int xv = x0, yv = y;
     asm volatile("" : "+v"(xv), "+v"(yv));
+    // (mode 9, likewise: what depends only on the frame size or the lane - the doubles of W / H and + 0.5 of the row set-up, record
+    //  and coverage addresses - is redone per visit instead of being held across all of them: 111 instead of 120 VGPRs)
+    int Wv = W, Hv = H, lanev = lane;
+    if constexpr (kDeform && OFDG_DEFORM_FENCE) asm volatile("" : "+s"(Wv), "+s"(Hv), "+v"(lanev));
+    WarpGeom g_visit;
+    if constexpr (kDeform && OFDG_DEFORM_FENCE) {
+      g_visit.tw = Wv; g_visit.th = Hv; g_visit.tw2 = 2 * Wv; g_visit.th2 = 2 * Hv;
+      g_visit.mx2 = ((g_visit.tw2 & (g_visit.tw2 - 1)) == 0) ? g_visit.tw2 - 1 : -1;
+      g_visit.my2 = ((g_visit.th2 & (g_visit.th2 - 1)) == 0) ? g_visit.th2 - 1 : -1;
+      g_visit.nshift = ((Wv & (Wv - 1)) == 0) ? (31 - __clz(Wv)) : -1;
+      g_visit.pitch = fg_pitch;
+    }
+    const WarpGeom& g = (kDeform && OFDG_DEFORM_FENCE) ? g_visit : g_frame;
+    const int lane = lanev;
+    const int W = Wv, H = Hv;
     uint32_t sh, c0w = 0, c1w = 0, recw = 0;
     if (vi < kPre) {
       sh = vi == 0 ? pre_sh[0] : pre_sh[kPre - 1];
@@ -1529,7 +1547,12 @@ __global__ __launch_bounds__(64) void compose_deform_kernel(
                              pool, bgpool, img0, img1, flow, frames, item_count, crops);
 }
 // Mode 9, W a power of two.
-__global__ __launch_bounds__(64) void compose_deform_pow2_kernel(
+#ifdef OFDG_DEFORM_WAVES
+#define OFDG_DEFORM_OCC __attribute__((amdgpu_waves_per_eu(OFDG_DEFORM_WAVES)))
+#else
+#define OFDG_DEFORM_OCC
+#endif
+__global__ __launch_bounds__(64) OFDG_DEFORM_OCC void compose_deform_pow2_kernel(
     RenderDims dm, const DevSample* __restrict__ samples, const DevObject* __restrict__ objects,
     const unsigned long long* __restrict__ blockmask, const uint8_t* __restrict__ cov, const uint32_t* __restrict__ pool,
     const uint32_t* __restrict__ bgpool, float* __restrict__ img0, float* __restrict__ img1, float* __restrict__ flow,
